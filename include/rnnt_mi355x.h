@@ -1,0 +1,116 @@
+/*
+ * rnnt_mi355x.h -- C ABI of librnnt_mi355x.so, a from-scratch RNN-Transducer
+ * loss (forward-backward + gradient) for AMD MI355X (gfx950).
+ *
+ * The boundary this library replaces is the one call the reference makes into
+ * its un-vendored dependency:
+ *
+ *     from warprnnt_tensorflow import rnnt_loss
+ *     rnnt_loss(acts, labels, input_length, label_length, blank_label=39)
+ *         reference rnnt/base/util.py:70-72   (Util.rnnt_lambda_func_v2)
+ *         reference rnnt/base/util.py:113-115 (Util.rnnt_lambda_func)
+ *
+ * together with the tf.nn.log_softmax the reference applies just before it
+ * (util.py:66, util.py:109) and the gradient TensorFlow chains back through
+ * both during training (rnnt/train.py:151-157), including the per-utterance
+ * upstream factor of the Keras batch mean (rnnt/keras_model.py:215-217).
+ *
+ * Conventions
+ *   - every pointer except `host_flags` and `out_bytes` is a DEVICE pointer;
+ *   - logits: float32 [B, maxT, maxU1, V], contiguous, V fastest
+ *     (acts of util.py:63 / :109 -- raw joint logits or log-probabilities:
+ *     log-softmax is idempotent so both give the same costs and gradients);
+ *   - labels: int32 [B, maxU1-1]; in_len, lab_len: int32 [B]
+ *     (dtypes of reference rnnt/keras_model.py:125-127);
+ *   - blank: any index in [0, V) (util.py:72 hard-codes 39);
+ *   - costs: float32 [B], cost_b = -log P(labels_b | logits_b);
+ *   - the gradient is d(sum_b grad_scale[b]*cost_b)/d(logits), i.e. it already
+ *     contains the log-softmax backward; cells with t >= in_len[b] or
+ *     u > lab_len[b] receive exact zeros;
+ *   - the caller owns every buffer including the workspace; no entry point
+ *     allocates or frees device memory, none keeps global state, all work is
+ *     enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and,
+ *     except rnnt_mi355x_read_status, none synchronises;
+ *   - every function returns an rnnt_mi355x_status; nothing throws or aborts.
+ *
+ * Limits: 1 <= maxU1 <= 512, B*maxT*maxU1 < 2^31, V >= 1.  Element offsets
+ * into logits are 64-bit.
+ */
+#ifndef RNNT_MI355X_H_
+#define RNNT_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  RNNT_MI355X_OK = 0,
+  RNNT_MI355X_INVALID_VALUE = 1,    /* null pointer, non-positive size, blank outside [0,V) ... */
+  RNNT_MI355X_UNSUPPORTED_SIZE = 2, /* maxU1 > 512 or B*maxT*maxU1 >= 2^31 */
+  RNNT_MI355X_LAUNCH_FAILURE = 3,   /* HIP reported an error at launch/copy */
+  RNNT_MI355X_BAD_INPUT_DATA = 4    /* device-side validation failed (see read_status) */
+} rnnt_mi355x_status;
+
+/* bits of the device-side validation word returned by rnnt_mi355x_read_status */
+#define RNNT_MI355X_FLAG_BAD_LENGTH 1 /* in_len[b] outside [1,maxT] or lab_len[b] outside [0,maxU1-1] */
+#define RNNT_MI355X_FLAG_BAD_LABEL 2  /* a used label outside [0,V) (clamped to 0 for the computation) */
+
+/* Bytes of workspace the other entry points need for a batch of this shape.
+ * Replaces the scratch allocation the dependency's op does internally behind
+ * rnnt_loss (call sites reference util.py:70-72, 113-115). */
+int rnnt_mi355x_workspace_bytes(int B, int maxT, int maxU1, size_t* out_bytes);
+
+/* costs[b] = -log P(labels_b | logits_b): the value rnnt_loss returns at
+ * reference util.py:71 / :114 (then reshaped to [B] at util.py:74 / :117).
+ * Leaves the lattice state in `workspace` for a later rnnt_mi355x_backward*. */
+int rnnt_mi355x_forward(const float* logits, const int32_t* labels, const int32_t* in_len, const int32_t* lab_len,
+                        int B, int maxT, int maxU1, int V, int blank, float* costs, void* workspace, void* hip_stream);
+
+/* grad = d(sum_b grad_scale[b]*cost_b)/d(logits) from the state a preceding
+ * rnnt_mi355x_forward on the SAME logits left in `workspace`.  `grad` may be
+ * the logits buffer itself (in place).  grad_scale: [B] floats or NULL (= 1);
+ * 1/B reproduces the Keras mean of reference keras_model.py:215-217.  This is
+ * the gradient registered on the dependency's op, the multiply by the
+ * upstream gradient and the log_softmax backward of util.py:66 / :109 in one
+ * pass. */
+int rnnt_mi355x_backward(const float* logits, float* grad, const int32_t* labels, const int32_t* in_len,
+                         const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank, const float* grad_scale,
+                         void* workspace, void* hip_stream);
+
+/* Same, overwriting the logits with their gradient. */
+int rnnt_mi355x_backward_inplace(float* logits_inout, const int32_t* labels, const int32_t* in_len,
+                                 const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
+                                 const float* grad_scale, void* workspace, void* hip_stream);
+
+/* forward + backward_inplace in one call: what one training step of
+ * reference rnnt/train.py:151-157 spends in the loss layer. */
+int rnnt_mi355x_loss_grad(float* logits_inout, const int32_t* labels, const int32_t* in_len, const int32_t* lab_len,
+                          int B, int maxT, int maxU1, int V, int blank, const float* grad_scale, float* costs,
+                          void* workspace, void* hip_stream);
+
+/* out2[0] = sum_b costs[b], out2[1] = sum of squared gradient elements of the
+ * last backward on this workspace (both float64, device memory).  These are
+ * the two scalars a data-parallel caller all-reduces: the batch loss of
+ * reference keras_model.py:215-217 and the gradient norm the optimizer's
+ * clipnorm needs (reference keras_model.py:209-213). */
+int rnnt_mi355x_reduce_scalars(const float* costs, int B, void* workspace, double* out2, void* hip_stream);
+
+/* Copies the device-side validation word to *host_flags (an OR of
+ * RNNT_MI355X_FLAG_*), waiting for the stream.  Returns
+ * RNNT_MI355X_BAD_INPUT_DATA when it is non-zero.  Corresponds to the
+ * exception the dependency's op raises on malformed inputs. */
+int rnnt_mi355x_read_status(const void* workspace, int32_t* host_flags, void* hip_stream);
+
+/* Human-readable text for a status code (static storage). */
+const char* rnnt_mi355x_status_string(int status);
+
+/* ABI version of this header: major*100 + minor. */
+int rnnt_mi355x_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNNT_MI355X_H_ */

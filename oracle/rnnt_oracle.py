@@ -1,0 +1,306 @@
+"""CPU oracle for the RNN-T (transducer) loss path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product path (rnnt_amd/) never does.
+
+What it restates
+----------------
+The reference computes its training loss in two Keras lambdas,
+``Util.rnnt_lambda_func`` (reference rnnt/base/util.py:93-117) and
+``Util.rnnt_lambda_func_v2`` (reference rnnt/base/util.py:53-74):
+
+  * crop the first ``shift = 2`` encoder frames and subtract 2 from the input
+    lengths                                   (util.py:62-64, util.py:100-102)
+  * form the joint ``y_trans[B,T,1,V] + y_pred[B,1,U+1,V]`` (util.py:107-109)
+  * ``tf.nn.log_softmax`` over the last axis  (util.py:66, util.py:109)
+  * reshape both length tensors to ``[B]``    (util.py:67-68, util.py:110-111)
+  * ``rnnt_loss(acts, labels, input_length, label_length, blank_label=39)``
+                                              (util.py:70-72, util.py:113-115)
+  * reshape the result to ``[B]``             (util.py:74, util.py:117)
+
+and Keras takes the batch mean of that vector through an identity loss
+(reference rnnt/keras_model.py:215-217).
+
+``rnnt_loss`` itself is NOT in the reference tree: it is the third-party
+package ``warprnnt_tensorflow`` (HawkAaron/warp-transducer TensorFlow binding),
+imported at util.py:70 and util.py:113, with no version pinned anywhere in the
+reference (no requirements/setup/lock file).  Its published algorithm is the
+transducer forward-backward of Graves, "Sequence Transduction with Recurrent
+Neural Networks" (arXiv:1211.3711), the paper the reference itself cites at
+rnnt/base/common.py:49-52.  This module restates that algorithm in float64
+numpy.
+
+PARITY PINNING: the reference holds no test, fixture or golden value for this
+path ("parity unpinned" with respect to the reference's own tests).  The oracle
+is pinned instead by (1) the public warp-transducer known-answer vector
+(B=1,T=2,U=2,V=5; costs 4.495666774 / 5.095666774 and their gradients), (2)
+brute-force enumeration of every alignment path on tiny lattices and (3)
+central finite differences of the cost; see tests/test_oracle.py.
+
+Conventions: ``logits`` is ``[B, T, U1, V]`` (U1 = max label length + 1),
+``labels`` ``[B, U1-1]``, ``input_lengths``/``label_lengths`` ``[B]``.  The
+gradient returned is d(cost_b)/d(logits) *through* the log-softmax, multiplied
+by ``grad_scale[b]`` (1/B reproduces the Keras batch mean, keras_model.py:216).
+Because log_softmax is idempotent the same numbers come out whether raw joint
+logits or already-log-softmaxed activations are passed in (util.py:66/109 pass
+the latter).
+"""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+
+NEG_INF = -np.inf
+
+
+def log_softmax(x: np.ndarray) -> np.ndarray:
+    """Row log-softmax over the last axis, the float64 analogue of
+    ``tf.nn.log_softmax`` at reference util.py:66 and util.py:109.  (The
+    reference's only in-tree log-softmax, ``Util.softmax(is_log=True)`` at
+    util.py:295-309, uses the same max-subtraction.)"""
+    x = np.asarray(x, dtype=np.float64)
+    m = np.max(x, axis=-1, keepdims=True)
+    return x - (m + np.log(np.sum(np.exp(x - m), axis=-1, keepdims=True)))
+
+
+def _lattice_logprobs(lp: np.ndarray, labels: np.ndarray, T: int, U: int, blank: int):
+    """Blank and label log-probabilities of one utterance's lattice.
+    lp: [T, U+1, V] log-probs.  Returns (lpb[T,U+1], lpl[T,U])."""
+    lpb = lp[:T, : U + 1, blank]
+    if U > 0:
+        lpl = lp[:T, :U, :][np.arange(T)[:, None], np.arange(U)[None, :], labels[:U][None, :]]
+    else:
+        lpl = np.zeros((T, 0))
+    return lpb, lpl
+
+
+def alpha_beta(lpb: np.ndarray, lpl: np.ndarray):
+    """Forward/backward lattice variables (Graves 2012, eqs. 16-18 and 19-21),
+    i.e. what ``rnnt_loss`` (call sites util.py:70-72, 113-115) evaluates.
+
+    alpha[0,0] = 0
+    alpha[t,u] = logaddexp(alpha[t-1,u] + lpb[t-1,u], alpha[t,u-1] + lpl[t,u-1])
+    beta[T-1,U] = lpb[T-1,U]
+    beta[t,u]  = logaddexp(beta[t+1,u] + lpb[t,u],   beta[t,u+1] + lpl[t,u])
+    ll = alpha[T-1,U] + lpb[T-1,U] = beta[0,0]
+    """
+    T, U1 = lpb.shape
+    U = U1 - 1
+    alpha = np.full((T, U1), NEG_INF)
+    beta = np.full((T, U1), NEG_INF)
+    alpha[0, 0] = 0.0
+    for t in range(T):
+        for u in range(U1):
+            if t == 0 and u == 0:
+                continue
+            a = alpha[t - 1, u] + lpb[t - 1, u] if t > 0 else NEG_INF
+            c = alpha[t, u - 1] + lpl[t, u - 1] if u > 0 else NEG_INF
+            alpha[t, u] = np.logaddexp(a, c)
+    beta[T - 1, U] = lpb[T - 1, U]
+    for t in range(T - 1, -1, -1):
+        for u in range(U, -1, -1):
+            if t == T - 1 and u == U:
+                continue
+            a = beta[t + 1, u] + lpb[t, u] if t < T - 1 else NEG_INF
+            c = beta[t, u + 1] + lpl[t, u] if u < U else NEG_INF
+            beta[t, u] = np.logaddexp(a, c)
+    ll = alpha[T - 1, U] + lpb[T - 1, U]
+    return alpha, beta, ll
+
+
+def alpha_beta_diag(lpb: np.ndarray, lpl: np.ndarray):
+    """Same recursion as :func:`alpha_beta`, vectorised along anti-diagonals
+    (cells with equal t+u are independent) so that BASELINE-sized lattices
+    (T=500, U=100) finish in well under a second."""
+    T, U1 = lpb.shape
+    U = U1 - 1
+    alpha = np.full((T, U1), NEG_INF)
+    beta = np.full((T, U1), NEG_INF)
+    alpha[0, 0] = 0.0
+    with np.errstate(invalid="ignore"):
+        for d in range(1, T + U):
+            u = np.arange(max(0, d - (T - 1)), min(U, d) + 1)
+            t = d - u
+            a = np.full(u.shape, NEG_INF)
+            c = np.full(u.shape, NEG_INF)
+            mt = t > 0
+            a[mt] = alpha[t[mt] - 1, u[mt]] + lpb[t[mt] - 1, u[mt]]
+            mu = u > 0
+            c[mu] = alpha[t[mu], u[mu] - 1] + lpl[t[mu], u[mu] - 1]
+            alpha[t, u] = np.logaddexp(a, c)
+        beta[T - 1, U] = lpb[T - 1, U]
+        for d in range(T + U - 2, -1, -1):
+            u = np.arange(max(0, d - (T - 1)), min(U, d) + 1)
+            t = d - u
+            a = np.full(u.shape, NEG_INF)
+            c = np.full(u.shape, NEG_INF)
+            mt = t < T - 1
+            a[mt] = beta[t[mt] + 1, u[mt]] + lpb[t[mt], u[mt]]
+            mu = u < U
+            c[mu] = beta[t[mu], u[mu] + 1] + lpl[t[mu], u[mu]]
+            beta[t, u] = np.logaddexp(a, c)
+    ll = alpha[T - 1, U] + lpb[T - 1, U]
+    return alpha, beta, ll
+
+
+def rnnt_loss_and_grad(logits, labels, input_lengths, label_lengths, blank, grad_scale=None):
+    """costs[B] and d(sum_b grad_scale[b]*cost_b)/d(logits) in float64.
+
+    Mirrors the call ``rnnt_loss(acts, labels, input_length, label_length,
+    blank_label)`` (reference util.py:70-72, 113-115) including the gradient
+    TensorFlow chains through ``tf.nn.log_softmax`` (util.py:66, 109):
+
+      dx[t,u,v] = s * ( gamma[t,u]*softmax[t,u,v]
+                        - [v==blank]    * exp(alpha+lpb+beta[t+1,u]-ll)
+                        - [v==y_{u+1}] * exp(alpha+lpl+beta[t,u+1]-ll) )
+
+    with gamma = exp(alpha+beta-ll); at the terminal cell the "next beta" of
+    the blank term is log 1.  Cells with t >= T_b or u > U_b get zero gradient.
+    If a label equals the blank index both subtractions land on the same v
+    (their sum) -- the dependency leaves that case undefined.
+    """
+    x = np.asarray(logits, dtype=np.float64)
+    B, maxT, maxU1, V = x.shape
+    labels = np.asarray(labels).reshape(B, -1)
+    Tl = np.asarray(input_lengths).reshape(B).astype(np.int64)
+    Ul = np.asarray(label_lengths).reshape(B).astype(np.int64)
+    if grad_scale is None:
+        grad_scale = np.ones(B)
+    grad_scale = np.asarray(grad_scale, dtype=np.float64).reshape(B)
+    costs = np.zeros(B)
+    grad = np.zeros_like(x)
+    for b in range(B):
+        T, U = int(Tl[b]), int(Ul[b])
+        assert 1 <= T <= maxT and 0 <= U <= maxU1 - 1
+        lp = log_softmax(x[b, :T, : U + 1, :])
+        lpb, lpl = _lattice_logprobs(lp, labels[b], T, U, blank)
+        alpha, beta, ll = alpha_beta_diag(lpb, lpl)
+        costs[b] = -ll
+        gamma = np.exp(alpha + beta - ll)
+        g = gamma[:, :, None] * np.exp(lp)
+        # blank transitions
+        pb = np.zeros((T, U + 1))
+        if T > 1:
+            pb[: T - 1, :] = np.exp(alpha[: T - 1, :] + lpb[: T - 1, :] + beta[1:, :] - ll)
+        pb[T - 1, U] = np.exp(alpha[T - 1, U] + lpb[T - 1, U] - ll)
+        g[:, :, blank] -= pb
+        if U > 0:
+            pl = np.exp(alpha[:, :U] + lpl + beta[:, 1:] - ll)
+            tt, uu = np.meshgrid(np.arange(T), np.arange(U), indexing="ij")
+            np.subtract.at(g, (tt, uu, labels[b][:U][None, :].repeat(T, 0)), pl)
+        grad[b, :T, : U + 1, :] = grad_scale[b] * g
+    return costs, grad
+
+
+def rnnt_lambda_func(y_trans, y_pred, labels, input_length, label_length, blank_label=39, grad_scale=None):
+    """Float64 restatement of ``Util.rnnt_lambda_func`` (reference
+    util.py:93-117): crop 2 frames, broadcast-add joint, log-softmax, loss.
+    Returns (costs[B], d/d y_trans [B,T0,V], d/d y_pred [B,U+1,V])."""
+    shift = 2  # util.py:100
+    y_trans = np.asarray(y_trans, dtype=np.float64)
+    y_pred = np.asarray(y_pred, dtype=np.float64)
+    yt = y_trans[:, shift:, :]  # util.py:101
+    in_len = np.asarray(input_length).reshape(-1) - shift  # util.py:102,110
+    lab_len = np.asarray(label_length).reshape(-1)  # util.py:111
+    acts = log_softmax(yt[:, :, None, :] + y_pred[:, None, :, :])  # util.py:107-109
+    costs, g = rnnt_loss_and_grad(acts, labels, in_len, lab_len, blank_label, grad_scale)
+    d_trans = np.zeros_like(y_trans)
+    d_trans[:, shift:, :] = g.sum(axis=2)
+    d_pred = g.sum(axis=1)
+    return costs, d_trans, d_pred
+
+
+def rnnt_lambda_func_v2(acts, labels, input_length, label_length, blank_label=39, grad_scale=None):
+    """Float64 restatement of ``Util.rnnt_lambda_func_v2`` (reference
+    util.py:53-74): the joint arrives already formed as [B,T0,U+1,V]."""
+    shift = 2  # util.py:62
+    acts = np.asarray(acts, dtype=np.float64)
+    a = log_softmax(acts[:, shift:, :, :])  # util.py:63,66
+    in_len = np.asarray(input_length).reshape(-1) - shift  # util.py:64,67
+    lab_len = np.asarray(label_length).reshape(-1)  # util.py:68
+    costs, g = rnnt_loss_and_grad(a, labels, in_len, lab_len, blank_label, grad_scale)
+    d_acts = np.zeros_like(acts)
+    d_acts[:, shift:, :, :] = g
+    return costs, d_acts
+
+
+# ---------------------------------------------------------------------------
+# Independent second opinions used to pin the oracle itself.
+# ---------------------------------------------------------------------------
+
+def brute_force_cost(logits, labels, T, U, blank):
+    """-log of the sum over EVERY alignment path of its probability (pure
+    Python, tiny lattices only).  A path is an interleaving of exactly U label
+    emissions and T blanks whose last symbol is the blank leaving (T-1, U)."""
+    lp = log_softmax(np.asarray(logits, dtype=np.float64)[:T, : U + 1, :])
+    total = NEG_INF
+    # choose positions of the U labels among the first T+U-1 moves; the final move is a blank
+    for lab_pos in itertools.combinations(range(T + U - 1), U):
+        lab_pos = set(lab_pos)
+        t = u = 0
+        s = 0.0
+        ok = True
+        for k in range(T + U - 1):
+            if k in lab_pos:
+                s += lp[t, u, labels[u]]
+                u += 1
+            else:
+                s += lp[t, u, blank]
+                t += 1
+                if t >= T:
+                    ok = False
+                    break
+        if not ok or t != T - 1 or u != U:
+            continue
+        s += lp[T - 1, U, blank]
+        total = np.logaddexp(total, s)
+    return -total
+
+
+def numeric_grad(logits, labels, input_lengths, label_lengths, blank, eps=1e-6):
+    """Central finite differences of sum_b cost_b w.r.t. every logit."""
+    x = np.array(logits, dtype=np.float64)
+    g = np.zeros_like(x)
+    it = np.nditer(x, flags=["multi_index"])
+    for _ in it:
+        i = it.multi_index
+        old = x[i]
+        x[i] = old + eps
+        cp = rnnt_loss_and_grad(x, labels, input_lengths, label_lengths, blank)[0].sum()
+        x[i] = old - eps
+        cm = rnnt_loss_and_grad(x, labels, input_lengths, label_lengths, blank)[0].sum()
+        x[i] = old
+        g[i] = (cp - cm) / (2 * eps)
+    return g
+
+
+# Public known-answer vector (warp-transducer / torchaudio unit test),
+# re-derived independently with brute_force_cost + numeric_grad in
+# tests/test_oracle.py before being trusted.
+KNOWN_ANSWER = {
+    "B": 1, "T": 2, "U": 2, "V": 5,
+    "labels": [[1, 2]],
+    "logits": [
+        [[[0.1, 0.6, 0.1, 0.1, 0.1], [0.1, 0.1, 0.6, 0.1, 0.1], [0.1, 0.1, 0.2, 0.8, 0.1]],
+         [[0.1, 0.6, 0.1, 0.1, 0.1], [0.1, 0.1, 0.2, 0.1, 0.1], [0.7, 0.1, 0.2, 0.1, 0.1]]]
+    ],
+    "blank0_cost": 4.495666774,
+    "blank0_grad": [
+        [[[-0.13116686, -0.3999268, 0.17703122, 0.17703122, 0.17703122],
+          [-0.18572754, 0.12247054, -0.18168408, 0.12247054, 0.12247054],
+          [-0.32091246, 0.06269139, 0.06928471, 0.12624497, 0.06269139]],
+         [[0.05456068, -0.21824272, 0.05456068, 0.05456068, 0.05456068],
+          [0.12073957, 0.12073957, -0.48295828, 0.12073957, 0.12073957],
+          [-0.6925882, 0.16871117, 0.18645468, 0.16871117, 0.16871117]]]
+    ],
+    "blank4_cost": 5.095666774,
+    "blank4_grad": [
+        [[[0.17703122, -0.3999268, 0.17703122, 0.17703122, -0.13116686],
+          [0.12247054, 0.12247054, -0.18168408, 0.12247054, -0.18572754],
+          [0.0626914, 0.0626914, 0.06928471, 0.12624497, -0.32091246]],
+         [[0.05456068, -0.21824272, 0.05456068, 0.05456068, 0.05456068],
+          [0.12073957, 0.12073957, -0.48295828, 0.12073957, 0.12073957],
+          [0.3074118, 0.16871117, 0.18645468, 0.16871117, -0.83128883]]]
+    ],
+}

@@ -1,0 +1,79 @@
+"""ctypes binding of librnnt_mi355x.so (C ABI: include/rnnt_mi355x.h).
+
+There is no fallback: if the HIP library is missing or fails to load, every
+use of the loss raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .build import LIB
+
+OK = 0
+INVALID_VALUE = 1
+UNSUPPORTED_SIZE = 2
+LAUNCH_FAILURE = 3
+BAD_INPUT_DATA = 4
+FLAG_BAD_LENGTH = 1
+FLAG_BAD_LABEL = 2
+
+_lib = None
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_META = [_i] * 5  # B, maxT, maxU1, V, blank
+
+_SIGNATURES = {
+    "rnnt_mi355x_workspace_bytes": (ctypes.c_int, [_i, _i, _i, ctypes.POINTER(_sz)]),
+    "rnnt_mi355x_forward": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp]),
+    "rnnt_mi355x_backward": (ctypes.c_int, [_vp] * 5 + _META + [_vp, _vp, _vp]),
+    "rnnt_mi355x_backward_inplace": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp]),
+    "rnnt_mi355x_loss_grad": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp]),
+    "rnnt_mi355x_reduce_scalars": (ctypes.c_int, [_vp, _i, _vp, _vp, _vp]),
+    "rnnt_mi355x_read_status": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
+    "rnnt_mi355x_status_string": (ctypes.c_char_p, [_i]),
+    "rnnt_mi355x_version": (ctypes.c_int, []),
+}
+
+
+class RNNTLibraryError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names every entry point include/rnnt_mi355x.h declares."""
+    return tuple(_SIGNATURES)
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise RNNTLibraryError(
+                f"{LIB} is missing: build it with `python -m rnnt_amd.build` (needs hipcc); "
+                "rnnt_amd has no CPU or eager fallback")
+        try:
+            handle = ctypes.CDLL(LIB)
+        except OSError as e:
+            raise RNNTLibraryError(f"cannot load {LIB}: {e}") from e
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def status_string(rc: int) -> str:
+    return lib().rnnt_mi355x_status_string(int(rc)).decode()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != OK:
+        raise RuntimeError(f"{what}: {status_string(rc)} (status {rc})")
+
+
+def workspace_bytes(B: int, maxT: int, maxU1: int) -> int:
+    out = _sz(0)
+    check(lib().rnnt_mi355x_workspace_bytes(B, maxT, maxU1, ctypes.byref(out)), "rnnt_mi355x_workspace_bytes")
+    return int(out.value)

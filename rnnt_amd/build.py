@@ -1,0 +1,45 @@
+"""Compiles rnnt_amd/csrc/rnnt_mi355x.hip into librnnt_mi355x.so for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in a CPU-only container; the
+built library stays in-tree (git-ignored) and travels with the source tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SRC = os.path.join(CSRC, "rnnt_mi355x.hip")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "rnnt_mi355x.h")
+LIB = os.path.join(CSRC, "librnnt_mi355x.so")
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build librnnt_mi355x.so")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in (SRC, HEADER))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-o", LIB, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,47 @@
+"""The two loss lambdas of the reference model, re-hosted on the MI355X loss.
+
+``Util.rnnt_lambda_func`` (reference rnnt/base/util.py:93-117) and
+``Util.rnnt_lambda_func_v2`` (reference rnnt/base/util.py:53-74) are what the
+Keras graph wraps in ``Lambda`` layers (reference rnnt/keras_model.py:165-168,
+186-188).  Same names, same argument lists, same crop / length handling /
+hard-coded default blank, same ``[B]`` result.  The explicit
+``tf.nn.log_softmax`` of util.py:66/109 is not executed as a separate pass:
+the loss kernels normalise each row themselves, which yields the same costs
+and, through autograd, the same gradients with respect to the lambda inputs.
+"""
+from __future__ import annotations
+
+from .loss import rnnt_loss
+
+SHIFT = 2  # "the first couple outputs of the RNN tend to be garbage" (util.py:60-62, 98-100)
+REFERENCE_BLANK_LABEL = 39  # util.py:72, util.py:115
+
+
+def rnnt_lambda_func(args, blank_label=REFERENCE_BLANK_LABEL):
+    """[y_trans[B,T0,V], y_pred[B,U+1,V], labels[B,U], input_length[B,1], label_length[B,1]] -> costs[B]
+    (reference util.py:93-117)."""
+    y_trans, y_pred, labels, input_length, label_length = args
+    y_trans = y_trans[:, SHIFT:, :]                      # util.py:101
+    input_length = input_length - SHIFT                  # util.py:102 (no in-place edit of the caller's tensor)
+    batch_size = y_trans.shape[0]                        # util.py:106
+    acts = y_trans.unsqueeze(2) + y_pred.unsqueeze(1)    # util.py:107-109 (BT1V + B1UV)
+    input_length = input_length.reshape(batch_size)      # util.py:110
+    label_length = label_length.reshape(batch_size)      # util.py:111
+    # acts is a fresh temporary nobody else reads: let backward reuse its storage
+    costs = rnnt_loss(acts, labels, input_length, label_length, blank_label, inplace=True)  # util.py:113-115
+    return costs.reshape(batch_size)                     # util.py:117
+
+
+def rnnt_lambda_func_v2(args, blank_label=REFERENCE_BLANK_LABEL):
+    """[acts[B,T0,U+1,V], labels[B,U], input_length[B,1], label_length[B,1]] -> costs[B]
+    (reference util.py:53-74); acts comes from the FC joint."""
+    acts, labels, input_length, label_length = args
+    batch_size = acts.shape[0]                           # util.py:58
+    acts = acts[:, SHIFT:, :, :]                         # util.py:63
+    input_length = input_length - SHIFT                  # util.py:64
+    input_length = input_length.reshape(batch_size)      # util.py:67
+    label_length = label_length.reshape(batch_size)      # util.py:68
+    cropped = acts.contiguous()                          # the crop is a strided view: one copy, then ours to overwrite
+    costs = rnnt_loss(cropped, labels, input_length, label_length, blank_label,
+                      inplace=cropped.data_ptr() != acts.data_ptr())  # util.py:70-72
+    return costs.reshape(batch_size)                     # util.py:74

@@ -1,0 +1,186 @@
+"""Host-side mirror of the reference's loss call surface over the C ABI.
+
+The reference calls, inside its Keras lambdas (reference
+rnnt/base/util.py:70-72 and :113-115),
+
+    rnnt_loss(acts, labels, input_length, label_length, blank_label=39)
+
+with acts [B,T,U+1,V] float32, labels [B,U] int32 and both lengths [B] int32,
+and gets back the per-utterance costs [B]; TensorFlow differentiates it with
+respect to acts only.  :func:`rnnt_loss` keeps that argument order, those
+shapes/dtypes and that result, as a ``torch.autograd.Function`` whose tensors
+live on an MI355X.  PyTorch is only plumbing here (device memory, the current
+HIP stream, autograd bookkeeping); all arithmetic happens in
+librnnt_mi355x.so.  There is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _prepare(acts, labels, input_lengths, label_lengths, blank_label):
+    if not isinstance(acts, torch.Tensor) or acts.dim() != 4:
+        raise ValueError("acts must be a [B, T, U+1, V] tensor")
+    if not acts.is_cuda:
+        raise RuntimeError("rnnt_amd.rnnt_loss runs on an AMD GPU only (acts must be a cuda/hip tensor); "
+                           "there is no CPU path")
+    if acts.dtype != torch.float32:
+        raise TypeError("acts must be float32 (reference rnnt/keras_model.py builds float32 graphs)")
+    B, T, U1, V = acts.shape
+    dev = acts.device
+    labels = torch.as_tensor(labels).to(device=dev, dtype=torch.int32).reshape(B, -1)
+    if labels.shape[1] != U1 - 1:
+        raise ValueError(f"labels must be [B, U] with U = acts.shape[2]-1 = {U1 - 1}, got {tuple(labels.shape)}")
+    labels = labels.contiguous()
+    il = torch.as_tensor(input_lengths)
+    ll = torch.as_tensor(label_lengths)
+    if il.numel() != B or ll.numel() != B:
+        raise ValueError("input_lengths and label_lengths must hold B elements")
+    # host-side validation is free when the lengths are host tensors
+    if not il.is_cuda and not ll.is_cuda:
+        ilh, llh = il.reshape(B).long(), ll.reshape(B).long()
+        if bool(((ilh < 1) | (ilh > T)).any()) or bool(((llh < 0) | (llh > U1 - 1)).any()):
+            raise ValueError("input_lengths must lie in [1, T] and label_lengths in [0, U]")
+    il = il.to(device=dev, dtype=torch.int32).reshape(B).contiguous()
+    ll = ll.to(device=dev, dtype=torch.int32).reshape(B).contiguous()
+    blank_label = int(blank_label)
+    if not 0 <= blank_label < V:
+        raise ValueError(f"blank_label {blank_label} outside [0, {V})")
+    return labels, il, ll, blank_label
+
+
+def _workspace(B, T, U1, device):
+    return torch.empty(_lib.workspace_bytes(B, T, U1), dtype=torch.uint8, device=device)
+
+
+def _raise_on_flags(ws, device):
+    flags = ctypes.c_int32(0)
+    rc = _lib.lib().rnnt_mi355x_read_status(_ptr(ws), ctypes.byref(flags), _stream_ptr(device))
+    if rc == _lib.BAD_INPUT_DATA:
+        what = []
+        if flags.value & _lib.FLAG_BAD_LENGTH:
+            what.append("an input/label length is out of range")
+        if flags.value & _lib.FLAG_BAD_LABEL:
+            what.append("a label is outside [0, V)")
+        raise ValueError("rnnt_loss: " + "; ".join(what))
+    _lib.check(rc, "rnnt_mi355x_read_status")
+
+
+class _RNNTLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, acts, labels, il, ll, blank, inplace, check_inputs):
+        B, T, U1, V = acts.shape
+        dev = acts.device
+        with torch.cuda.device(dev):
+            ws = _workspace(B, T, U1, dev)
+            costs = torch.empty(B, dtype=torch.float32, device=dev)
+            rc = _lib.lib().rnnt_mi355x_forward(_ptr(acts), _ptr(labels), _ptr(il), _ptr(ll), B, T, U1, V, blank,
+                                                _ptr(costs), _ptr(ws), _stream_ptr(dev))
+            _lib.check(rc, "rnnt_mi355x_forward")
+            if check_inputs:
+                _raise_on_flags(ws, dev)
+        ctx.acts, ctx.labels, ctx.il, ctx.ll, ctx.ws = acts, labels, il, ll, ws
+        ctx.blank, ctx.inplace = blank, inplace
+        return costs
+
+    @staticmethod
+    def backward(ctx, grad_costs):
+        acts = ctx.acts
+        if acts is None:
+            raise RuntimeError("rnnt_loss: backward called twice (the lattice state was released)")
+        B, T, U1, V = acts.shape
+        dev = acts.device
+        with torch.cuda.device(dev):
+            scale = grad_costs.to(device=dev, dtype=torch.float32).reshape(B).contiguous()
+            grad = acts if ctx.inplace else torch.empty_like(acts)
+            rc = _lib.lib().rnnt_mi355x_backward(_ptr(acts), _ptr(grad), _ptr(ctx.labels), _ptr(ctx.il), _ptr(ctx.ll),
+                                                 B, T, U1, V, ctx.blank, _ptr(scale), _ptr(ctx.ws), _stream_ptr(dev))
+            _lib.check(rc, "rnnt_mi355x_backward")
+        ctx.acts = ctx.ws = None
+        return grad, None, None, None, None, None, None
+
+
+def rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0, *, inplace=False, check_inputs=True):
+    """Per-utterance transducer costs ``[B]``; same positional signature as the
+    ``rnnt_loss`` the reference imports (reference rnnt/base/util.py:70-72,
+    113-115), differentiable w.r.t. ``acts`` only.
+
+    acts may hold raw joint logits or log-probabilities (the reference passes
+    the latter, util.py:66/109): log-softmax is idempotent, so costs and
+    gradients are identical, and the returned gradient is always the one with
+    respect to the tensor passed in.
+
+    inplace=True lets backward overwrite ``acts`` with its gradient (saves a
+    [B,T,U+1,V] allocation); only legal when nothing else reads ``acts`` later.
+    check_inputs=True reads a 4-byte validation word back after the forward
+    (one stream sync) and raises ValueError on malformed lengths/labels.
+    """
+    labels, il, ll, blank = _prepare(acts, labels, input_lengths, label_lengths, blank_label)
+    if not acts.is_contiguous():
+        acts = acts.contiguous()
+    return _RNNTLossFn.apply(acts, labels, il, ll, blank, bool(inplace), bool(check_inputs))
+
+
+def rnnt_loss_grad_(acts, labels, input_lengths, label_lengths, blank_label=0, grad_scale=None, *, workspace=None,
+                    check_inputs=False):
+    """Fused forward+backward without autograd: returns costs ``[B]`` and
+    overwrites ``acts`` with d(sum_b grad_scale[b]*cost_b)/d(acts).  This is the
+    call bench.py times (one rnnt_mi355x_loss_grad)."""
+    labels, il, ll, blank = _prepare(acts, labels, input_lengths, label_lengths, blank_label)
+    if not acts.is_contiguous():
+        raise ValueError("rnnt_loss_grad_ needs contiguous acts (it writes the gradient in place)")
+    B, T, U1, V = acts.shape
+    dev = acts.device
+    with torch.cuda.device(dev):
+        ws = workspace if workspace is not None else _workspace(B, T, U1, dev)
+        costs = torch.empty(B, dtype=torch.float32, device=dev)
+        gs = None if grad_scale is None else torch.as_tensor(grad_scale).to(device=dev, dtype=torch.float32).reshape(B).contiguous()
+        rc = _lib.lib().rnnt_mi355x_loss_grad(_ptr(acts), _ptr(labels), _ptr(il), _ptr(ll), B, T, U1, V, blank,
+                                              _ptr(gs), _ptr(costs), _ptr(ws), _stream_ptr(dev))
+        _lib.check(rc, "rnnt_mi355x_loss_grad")
+        if check_inputs:
+            _raise_on_flags(ws, dev)
+    return costs
+
+
+def reduce_scalars(costs, workspace):
+    """float64 [2] device tensor {sum of costs, sum of squared gradient
+    elements of the last backward on `workspace`}."""
+    dev = costs.device
+    out = torch.empty(2, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().rnnt_mi355x_reduce_scalars(_ptr(costs), costs.numel(), _ptr(workspace), _ptr(out), _stream_ptr(dev))
+        _lib.check(rc, "rnnt_mi355x_reduce_scalars")
+    return out
+
+
+class RNNTLoss(torch.nn.Module):
+    """Module form: ``RNNTLoss(blank_label=39)(acts, labels, in_len, lab_len)``
+    returns the batch-mean cost, the scalar Keras minimises through its
+    identity loss (reference rnnt/keras_model.py:215-217)."""
+
+    def __init__(self, blank_label=39, reduction="mean", inplace=False):
+        super().__init__()
+        if reduction not in ("mean", "sum", "none"):
+            raise ValueError("reduction must be mean, sum or none")
+        self.blank_label, self.reduction, self.inplace = int(blank_label), reduction, inplace
+
+    def forward(self, acts, labels, input_lengths, label_lengths):
+        costs = rnnt_loss(acts, labels, input_lengths, label_lengths, self.blank_label, inplace=self.inplace)
+        if self.reduction == "mean":
+            return costs.mean()
+        if self.reduction == "sum":
+            return costs.sum()
+        return costs

@@ -1,0 +1,132 @@
+"""Pins the float64 oracle (oracle/rnnt_oracle.py) before anything is compared
+with it: public known-answer vector, brute-force path enumeration, finite
+differences, diagonal-vs-plain recursion, and the committed golden fixtures."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import rnnt_oracle as orc
+
+
+def _ka():
+    K = orc.KNOWN_ANSWER
+    return np.array(K["logits"]), np.array(K["labels"]), K
+
+
+@pytest.mark.parametrize("blank,key", [(0, "blank0"), (4, "blank4")])
+def test_known_answer_vector(blank, key):
+    x, lab, K = _ka()
+    costs, grad = orc.rnnt_loss_and_grad(x, lab, [2], [2], blank)
+    assert abs(costs[0] - K[key + "_cost"]) < 1e-8
+    np.testing.assert_allclose(grad, np.array(K[key + "_grad"]), atol=2e-8)
+
+
+@pytest.mark.parametrize("blank", [0, 4])
+def test_known_answer_rederived_independently(blank):
+    """The public vector is not taken on trust: brute-force path enumeration
+    and finite differences must give the same numbers."""
+    x, lab, K = _ka()
+    key = "blank0" if blank == 0 else "blank4"
+    assert abs(orc.brute_force_cost(x[0], lab[0], 2, 2, blank) - K[key + "_cost"]) < 1e-8
+    ng = orc.numeric_grad(x, lab, [2], [2], blank)
+    np.testing.assert_allclose(ng, np.array(K[key + "_grad"]), atol=5e-8)
+
+
+@pytest.mark.parametrize("T,U,V,blank", [(1, 0, 3, 0), (1, 3, 4, 2), (4, 0, 3, 1), (3, 3, 5, 4), (4, 2, 6, 0), (2, 4, 3, 1)])
+def test_brute_force_paths(T, U, V, blank):
+    rng = np.random.default_rng(T * 100 + U * 10 + V)
+    x = rng.standard_normal((1, T, U + 1, V)) * 2
+    lab = rng.integers(0, V - 1, size=(1, max(U, 1)))
+    lab[lab >= blank] += 1
+    lab = lab[:, :U]
+    costs, _ = orc.rnnt_loss_and_grad(x, lab.reshape(1, U), [T], [U], blank)
+    assert abs(costs[0] - orc.brute_force_cost(x[0], lab[0], T, U, blank)) < 1e-10
+
+
+def test_finite_differences_ragged():
+    rng = np.random.default_rng(7)
+    B, T, U, V, blank = 2, 4, 3, 5, 2
+    x = rng.standard_normal((B, T, U + 1, V))
+    lab = np.array([[0, 1, 3], [4, 4, 0]])
+    il, ll = [4, 3], [3, 1]
+    _, g = orc.rnnt_loss_and_grad(x, lab, il, ll, blank)
+    ng = orc.numeric_grad(x, lab, il, ll, blank)
+    np.testing.assert_allclose(g, ng, atol=1e-7)
+    assert np.all(g[1, 3:] == 0) and np.all(g[1, :, 2:] == 0)  # padded cells
+
+
+def test_diag_recursion_equals_plain():
+    rng = np.random.default_rng(3)
+    lpb = -rng.uniform(0.1, 3, (9, 6))
+    lpl = -rng.uniform(0.1, 3, (9, 5))
+    a0, b0, l0 = orc.alpha_beta(lpb, lpl)
+    a1, b1, l1 = orc.alpha_beta_diag(lpb, lpl)
+    np.testing.assert_allclose(a0, a1, atol=1e-12)
+    np.testing.assert_allclose(b0, b1, atol=1e-12)
+    assert abs(l0 - l1) < 1e-12 and abs(b0[0, 0] - l0) < 1e-10
+
+
+def test_log_softmax_idempotent_inputs():
+    """Passing log-probs (what the reference does, util.py:66/109) or raw
+    logits gives the same costs and the same gradient."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 5, 4, 7))
+    lab = rng.integers(1, 7, (2, 3))
+    c0, g0 = orc.rnnt_loss_and_grad(x, lab, [5, 4], [3, 2], 0)
+    c1, g1 = orc.rnnt_loss_and_grad(orc.log_softmax(x), lab, [5, 4], [3, 2], 0)
+    np.testing.assert_allclose(c0, c1, atol=1e-12)
+    np.testing.assert_allclose(g0, g1, atol=1e-12)
+
+
+def test_gradient_rows_sum_to_zero_and_blank_occupancy():
+    rng = np.random.default_rng(5)
+    T, U, V = 6, 4, 9
+    x = rng.standard_normal((1, T, U + 1, V))
+    lab = rng.integers(1, V, (1, U))
+    _, g = orc.rnnt_loss_and_grad(x, lab, [T], [U], 0)
+    np.testing.assert_allclose(g.sum(-1), 0, atol=1e-12)
+
+
+def test_label_equal_to_blank_sums_both_terms():
+    x = np.array(orc.KNOWN_ANSWER["logits"])
+    lab = np.array([[0, 2]])  # first label equals blank index 0
+    c, g = orc.rnnt_loss_and_grad(x, lab, [2], [2], 0)
+    assert np.isfinite(c).all() and abs(g.sum()) < 1e-12
+
+
+def test_lambda_funcs_follow_reference_contract():
+    rng = np.random.default_rng(2)
+    B, T0, U, V = 2, 7, 3, 6
+    yt = rng.standard_normal((B, T0, V))
+    yp = rng.standard_normal((B, U + 1, V))
+    lab = rng.integers(0, V - 1, (B, U))
+    il = np.array([[7], [6]])
+    ll = np.array([[3], [2]])
+    costs, dt, dp = orc.rnnt_lambda_func(yt, yp, lab, il, ll, blank_label=V - 1)
+    joint = yt[:, :, None, :] + yp[:, None, :, :]
+    c2, da = orc.rnnt_lambda_func_v2(joint, lab, il, ll, blank_label=V - 1)
+    np.testing.assert_allclose(costs, c2, atol=1e-12)
+    assert np.all(dt[:, :2] == 0) and np.all(da[:, :2] == 0)  # cropped frames get no gradient
+    np.testing.assert_allclose(dt, da.sum(2), atol=1e-12)
+    np.testing.assert_allclose(dp, da.sum(1), atol=1e-12)
+    # direct call on the cropped tensor with lengths-2
+    c3, _ = orc.rnnt_loss_and_grad(joint[:, 2:], lab, il.reshape(-1) - 2, ll.reshape(-1), V - 1)
+    np.testing.assert_allclose(costs, c3, atol=1e-12)
+
+
+def test_golden_fixtures_match_oracle(golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "*.npz")))
+    assert len(files) >= 9
+    for f in files:
+        z = np.load(f)
+        if os.path.basename(f) == "known_answer.npz":
+            for blank, key in ((0, "blank0"), (4, "blank4")):
+                c, g = orc.rnnt_loss_and_grad(z["logits"], z["labels"], z["in_len"], z["lab_len"], blank)
+                assert abs(c[0] - float(z[key + "_cost"])) < 1e-6
+                np.testing.assert_allclose(g, z[key + "_grad"], atol=1e-7)
+            continue
+        c, g = orc.rnnt_loss_and_grad(z["logits"], z["labels"], z["in_len"], z["lab_len"], int(z["blank"]), z["grad_scale"])
+        np.testing.assert_allclose(c, z["costs"], rtol=1e-12)
+        np.testing.assert_allclose(g, z["grad"], atol=1e-12)
