@@ -8,7 +8,10 @@ from __future__ import annotations
 import ctypes
 import os
 
-from .build import LIB
+from .build import LIB as _DEFAULT_LIB
+
+# RNNT_MI355X_LIB selects another build of the same library (debug / experiment builds).
+LIB = os.environ.get("RNNT_MI355X_LIB") or _DEFAULT_LIB
 
 OK = 0
 INVALID_VALUE = 1

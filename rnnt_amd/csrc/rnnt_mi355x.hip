@@ -31,31 +31,44 @@ namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr double kLn2 = 0.6931471805599453;
-constexpr double kNeg = -1.0e30;   // "log 0" that stays finite under addition
+constexpr float kNegF = -1.0e30f;  // "log 0" that stays finite under addition
+constexpr double kNeg = -1.0e30;
 constexpr int kMaxU1 = 512;
-constexpr int kRowBlock = 256;     // threads per block of the streaming kernels
-constexpr int kMaxRowBlocks = 2048;  // 256 CUs x 8 blocks
-constexpr int kStatusInts = 64;
+constexpr int kRowBlock = 256;  // threads per block of the streaming kernels
+constexpr int kRowWaves = kRowBlock / 64;
+
+// First bytes of the workspace, written on the device.
+struct Header {
+  int32_t flags;          // OR of RNNT_MI355X_FLAG_*
+  int32_t n_partial;      // entries of `partial` the last k_grad wrote
+  uint64_t partial_off;   // byte offset of `partial` from the workspace base
+  int32_t pad[60];
+};
+static_assert(sizeof(Header) == 256, "header is one 256-byte block");
 
 struct Ws {
-  int32_t* status;   // [kStatusInts]
-  double* ll;        // [2][B]  log2-likelihood from alpha / from beta
-  float* partial;    // [kMaxRowBlocks] per-block sum of squared gradients
-  float* lse;        // [B][D][U1s] log2-sum-exp2 of the row
-  float* lpb;        // [B][D][U1s] log2 P(blank | t,u)
-  float* lpl;        // [B][D][U1s] log2 P(label u+1 | t,u)
-  double* alpha;     // [B][D][U1s]
-  double* beta;      // [B][D][U1s]
-  int D;             // diagonals = maxT + maxU1 - 1
-  int U1s;           // row stride (maxU1 rounded up to 8)
+  Header* hdr;
+  double* ll;      // [2][B]  log2-likelihood from alpha / from beta
+  float* partial;  // [B*maxT] per-block sum of squared gradient elements
+  float4* rec;     // [B][maxT][maxU1] {log2 P(blank|t,u), log2 P(label u+1|t,u), log2-sum-exp2 of the row, 0}
+  double* alpha;   // [B][D][U1s]
+  double* beta;    // [B][D][U1s]
+  size_t partial_off;
+  int D;    // diagonals = maxT + maxU1 - 1
+  int U1s;  // row stride = 64 * sweep_cols_per_lane(maxU1)
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Lattice columns each lane of a sweep wavefront owns (1, 2, 4 or 8).  The
+// row stride of the per-cell arrays is 64 times this, so that every lane of a
+// sweep can load and store its columns unconditionally.
+inline int sweep_cols_per_lane(int maxU1) { return maxU1 <= 64 ? 1 : maxU1 <= 128 ? 2 : maxU1 <= 256 ? 4 : 8; }
+
 // Lays the workspace out; returns total bytes.  base may be null (size query).
 size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w) {
   const int D = maxT + maxU1 - 1;
-  const int U1s = (maxU1 + 7) / 8 * 8;
+  const int U1s = 64 * sweep_cols_per_lane(maxU1);
   const size_t plane = (size_t)B * D * U1s;
   char* p = static_cast<char*>(base);
   size_t off = 0;
@@ -64,28 +77,34 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w) {
     off = align_up(off + bytes, 256);
     return o;
   };
-  const size_t o_status = take(sizeof(int32_t) * kStatusInts);
-  const size_t o_partial = take(sizeof(float) * kMaxRowBlocks);
+  const size_t o_hdr = take(sizeof(Header));
   const size_t o_ll = take(sizeof(double) * 2 * B);
-  const size_t o_lse = take(sizeof(float) * plane);
-  const size_t o_lpb = take(sizeof(float) * plane);
-  const size_t o_lpl = take(sizeof(float) * plane);
+  const size_t o_partial = take(sizeof(float) * (size_t)B * maxT);
+  const size_t o_rec = take(sizeof(float4) * (size_t)B * maxT * maxU1);
   const size_t o_alpha = take(sizeof(double) * plane);
   const size_t o_beta = take(sizeof(double) * plane);
   if (w) {
-    w->status = reinterpret_cast<int32_t*>(p + o_status);
+    w->hdr = reinterpret_cast<Header*>(p + o_hdr);
     w->ll = reinterpret_cast<double*>(p + o_ll);
     w->partial = reinterpret_cast<float*>(p + o_partial);
-    w->lse = reinterpret_cast<float*>(p + o_lse);
-    w->lpb = reinterpret_cast<float*>(p + o_lpb);
-    w->lpl = reinterpret_cast<float*>(p + o_lpl);
+    w->rec = reinterpret_cast<float4*>(p + o_rec);
     w->alpha = reinterpret_cast<double*>(p + o_alpha);
     w->beta = reinterpret_cast<double*>(p + o_beta);
+    w->partial_off = o_partial;
     w->D = D;
     w->U1s = U1s;
   }
   return off;
 }
+
+// Geometry of the streaming kernels: one block per (utterance, TT frames).
+struct RowGeom {
+  int maxT, maxU1, V, blank;
+  int TT;     // frames per block
+  int nTB;    // frame blocks per utterance
+  int npass;  // passes of NC chunks per lane over one row
+  int nblocks;
+};
 
 // ---------------------------------------------------------------------------
 // device helpers
@@ -103,10 +122,15 @@ __device__ __forceinline__ void utt_dims(const int32_t* in_len, const int32_t* l
   U = ok ? u : 0;
 }
 
+typedef float f4v __attribute__((ext_vector_type(4)));
 template <int VEC>
 __device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
   if constexpr (VEC == 4) {
+#ifdef EXP_NT_LOADS
+    const f4v q = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+#else
     const float4 q = *reinterpret_cast<const float4*>(p);
+#endif
     v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
   } else if constexpr (VEC == 2) {
     const float2 q = *reinterpret_cast<const float2*>(p);
@@ -119,7 +143,12 @@ __device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
 template <int VEC>
 __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
   if constexpr (VEC == 4) {
+#ifdef EXP_NT_STORES
+    f4v q = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(q, reinterpret_cast<f4v*>(p));
+#else
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
   } else if constexpr (VEC == 2) {
     *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
   } else {
@@ -140,136 +169,181 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-// Position of a logits row in the lattice.
-struct RowPos {
-  int b, t, u;
-  int T, U;
-  bool in_range;  // row < B*maxT*maxU1
-  bool valid;     // a real lattice cell of utterance b
-};
-
-__device__ __forceinline__ RowPos decode_row(long long row, long long total_rows, int maxT, int maxU1,
-                                             const int32_t* in_len, const int32_t* lab_len) {
-  RowPos p;
-  p.in_range = row < total_rows;
-  const unsigned r = p.in_range ? (unsigned)row : 0u;
-  const unsigned per_b = (unsigned)maxT * (unsigned)maxU1;
-  p.b = (int)(r / per_b);
-  const unsigned rem = r - (unsigned)p.b * per_b;
-  p.t = (int)(rem / (unsigned)maxU1);
-  p.u = (int)(rem - (unsigned)p.t * (unsigned)maxU1);
-  utt_dims(in_len, lab_len, p.b, maxT, maxU1, p.T, p.U);
-  p.valid = p.in_range && (p.t < p.T) && (p.u <= p.U);
-  return p;
-}
-
-// ---------------------------------------------------------------------------
-// k_lse: row log-sum-exp + blank/label log-probs.
-//
-// A wavefront is split into R = 64/L groups of L lanes; each group owns one
-// row, lane j of the group owns the VEC-wide chunks j, j+L, j+2L, ...  One
-// wave iteration covers G*R consecutive rows with G*NC vector loads in flight
-// per lane (4 x 16 B for V % 4 == 0).
-// ---------------------------------------------------------------------------
-template <int VEC, int L, int NC, int G>
-__global__ __launch_bounds__(kRowBlock) void k_lse(const float* __restrict__ x, const int32_t* __restrict__ labels,
-                                                   const int32_t* __restrict__ in_len,
-                                                   const int32_t* __restrict__ lab_len, int B, int maxT, int maxU1,
-                                                   int V, int blank, Ws w, long long nit) {
-  constexpr int R = 64 / L;
-  const int lane = threadIdx.x & 63;
-  const int j = lane % L;
-  const int r = lane / L;
-  const long long wave = (long long)blockIdx.x * (kRowBlock / 64) + (threadIdx.x >> 6);
-  const long long nwaves = (long long)gridDim.x * (kRowBlock / 64);
-  const int nchunk = V / VEC;
-  const int cpl = (nchunk + L - 1) / L;  // chunks per lane per row
-  const long long total_rows = (long long)B * maxT * maxU1;
-
-  for (long long it = wave; it < nit; it += nwaves) {
-    RowPos pos[G];
-    const float* rowp[G];
-    float extra[G];  // lane j==0: logit of blank; lane j==1: logit of the next label
-    float m_run[G], s_run[G];
+// Rows of the current tile owned by this lane, advanced incrementally (no
+// division in the loop).  Row rho of the block is frame t0 + tt, column uu.
+template <int G>
+struct RowCursor {
+  int rho[G], tt[G], uu[G];
+  int pass;
+  __device__ __forceinline__ void init(int first_row, int rows_apart, int maxU1) {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const long long row = (it * G + g) * R + r;
-      pos[g] = decode_row(row, total_rows, maxT, maxU1, in_len, lab_len);
-      rowp[g] = x + (size_t)(pos[g].in_range ? row : 0) * (size_t)V;
-      m_run[g] = -INFINITY;
-      s_run[g] = 0.f;
-      extra[g] = 0.f;
-      if (pos[g].valid) {
-        if (j == 0) {
-          extra[g] = rowp[g][blank];
-        } else if (j == 1 && pos[g].u < pos[g].U) {
-          int lab = labels[(size_t)pos[g].b * (maxU1 - 1) + pos[g].u];
-          if (lab < 0 || lab >= V) {
-            atomicOr(w.status, RNNT_MI355X_FLAG_BAD_LABEL);
-            lab = 0;
-          }
-          extra[g] = rowp[g][lab];
-        }
-      }
+      rho[g] = first_row + g * rows_apart;
+      tt[g] = rho[g] / maxU1;
+      uu[g] = rho[g] - tt[g] * maxU1;
     }
-    for (int k0 = 0; k0 < cpl; k0 += NC) {
-      float v[G][NC][VEC];
+    pass = 0;
+  }
+  __device__ __forceinline__ void advance(int npass, int S, int sq, int sr, int maxU1) {
+    if (++pass == npass) {
+      pass = 0;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-          const int c = j + L * (k0 + i);
-          if (pos[g].valid && c < nchunk) {
-            load_vec<VEC>(rowp[g] + (size_t)c * VEC, v[g][i]);
-          } else {
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) v[g][i][q] = -INFINITY;
-          }
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < NC; ++i)
-#pragma unroll
-          for (int q = 0; q < VEC; ++q) mx = fmaxf(mx, v[g][i][q]);
-        mx = group_max<L>(mx);
-        // rows with no valid cell keep m = 0 so that nothing below is NaN
-        const float m_new = pos[g].valid ? fmaxf(m_run[g], mx) : 0.f;
-        const float m2 = m_new * kLog2e;
-        float s = s_run[g] * fast_exp2(m_run[g] * kLog2e - m2);
-#pragma unroll
-        for (int i = 0; i < NC; ++i)
-#pragma unroll
-          for (int q = 0; q < VEC; ++q) s += fast_exp2(__builtin_fmaf(v[g][i][q], kLog2e, -m2));
-        m_run[g] = m_new;
-        s_run[g] = s;
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float s_all = group_sum<L>(s_run[g]);
-      const float lse2 = m_run[g] * kLog2e + fast_log2(s_all);
-      if (pos[g].valid && j < 2) {
-        const size_t ci = ((size_t)pos[g].b * w.D + (pos[g].t + pos[g].u)) * w.U1s + pos[g].u;
-        const float lp2 = __builtin_fmaf(extra[g], kLog2e, -lse2);
-        if (j == 0) {
-          w.lse[ci] = lse2;
-          w.lpb[ci] = lp2;
-        } else if (pos[g].u < pos[g].U) {
-          w.lpl[ci] = lp2;
+        rho[g] += S;
+        tt[g] += sq;
+        uu[g] += sr;
+        if (uu[g] >= maxU1) {
+          uu[g] -= maxU1;
+          tt[g] += 1;
         }
       }
     }
   }
+};
+
+// ---------------------------------------------------------------------------
+// k_lse: row log-sum-exp + blank/label log-probs.
+//
+// One block per (utterance, TT frames): the block's rows are contiguous in
+// memory and share T_b/U_b.  A wavefront is split into R = 64/L groups of L
+// lanes; each group owns one row per tile, lane j of the group owns the
+// VEC-wide chunks j, j+L, j+2L, ...  A tile is G*R rows x NC chunks per lane
+// (G*NC = 4 vector loads in flight per lane); tiles are software-pipelined two
+// deep so that a wave always has the next tile's loads outstanding while it
+// reduces the current one.
+// ---------------------------------------------------------------------------
+template <int VEC, int NC, int G>
+struct LseTile {
+  float v[G][NC][VEC];
+  float xb[G], xl[G];  // lane j==0, pass 0: logits of blank and of the next label
+  int rho[G];          // row inside the block, -1 = the row holds no cell
+  int pass;
+};
+
+template <int VEC, int L, int NC, int G>
+__global__ __launch_bounds__(kRowBlock) void k_lse(const float* __restrict__ x, const int32_t* __restrict__ labels,
+                                                   const int32_t* __restrict__ in_len,
+                                                   const int32_t* __restrict__ lab_len, RowGeom gm, Ws w) {
+  constexpr int R = 64 / L;
+  constexpr int S = kRowWaves * G * R;  // rows per block iteration
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane % L, r = lane / L;
+  const int b = blockIdx.x / gm.nTB;
+  const int t0 = (blockIdx.x - b * gm.nTB) * gm.TT;
+  int T, U;
+  utt_dims(in_len, lab_len, b, gm.maxT, gm.maxU1, T, U);
+  if (t0 >= T) return;  // frames at or beyond T_b hold no lattice cell
+  const int rows_blk = (min(t0 + gm.TT, T) - t0) * gm.maxU1;
+  const int ntiles = ((rows_blk + S - 1) / S) * gm.npass;
+  const int V = gm.V, blank = gm.blank, maxU1 = gm.maxU1, npass = gm.npass;
+  const int nchunk = V / VEC;
+  const int sq = S / maxU1, sr = S % maxU1;
+  const float* xblk = x + (size_t)(b * gm.maxT + t0) * maxU1 * V;
+  extern __shared__ float4 recs[];  // this block's records, written out in one coalesced burst at the end
+
+  RowCursor<G> cur;
+  cur.init(wv * G * R + r, R, maxU1);
+
+  float m_run[G], s_run[G], exb[G], exl[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) { m_run[g] = -INFINITY; s_run[g] = 0.f; exb[g] = 0.f; exl[g] = 0.f; }
+
+  auto issue = [&](LseTile<VEC, NC, G>& tl) {
+    tl.pass = cur.pass;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const bool valid = (cur.rho[g] < rows_blk) & (cur.uu[g] <= U);
+      tl.rho[g] = valid ? cur.rho[g] : -1;
+      const float* rp = xblk + (size_t)(valid ? cur.rho[g] : 0) * V;
+      tl.xb[g] = 0.f;
+      tl.xl[g] = 0.f;
+      if (cur.pass == 0 && valid && j == 0) {
+        tl.xb[g] = rp[blank];
+        if (cur.uu[g] < U) {
+          int lab = labels[(size_t)b * (maxU1 - 1) + cur.uu[g]];
+          if (lab < 0 || lab >= V) {
+            atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
+            lab = 0;
+          }
+          tl.xl[g] = rp[lab];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int c = j + L * (cur.pass * NC + i);
+        if (valid && c < nchunk) {
+          load_vec<VEC>(rp + (size_t)c * VEC, tl.v[g][i]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) tl.v[g][i][q] = -INFINITY;
+        }
+      }
+    }
+    cur.advance(npass, S, sq, sr, maxU1);
+  };
+
+  auto consume = [&](const LseTile<VEC, NC, G>& tl) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (tl.pass == 0) {
+        m_run[g] = -INFINITY;
+        s_run[g] = 0.f;
+        exb[g] = tl.xb[g];
+        exl[g] = tl.xl[g];
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) mx = fmaxf(mx, tl.v[g][i][q]);
+      mx = group_max<L>(mx);
+      // rows without a cell keep m = 0 so that nothing below is NaN
+      const float m_new = (tl.rho[g] >= 0) ? fmaxf(m_run[g], mx) : 0.f;
+      const float m2 = m_new * kLog2e;
+      float s = s_run[g] * fast_exp2(m_run[g] * kLog2e - m2);
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) s += fast_exp2(__builtin_fmaf(tl.v[g][i][q], kLog2e, -m2));
+      m_run[g] = m_new;
+      s_run[g] = s;
+    }
+    if (tl.pass == npass - 1) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float s_all = group_sum<L>(s_run[g]);
+        const float lse2 = m_run[g] * kLog2e + fast_log2(s_all);
+        if (tl.rho[g] >= 0 && j == 0)
+          recs[tl.rho[g]] = make_float4(__builtin_fmaf(exb[g], kLog2e, -lse2), __builtin_fmaf(exl[g], kLog2e, -lse2),
+                                        lse2, 0.f);
+      }
+    }
+  };
+
+  LseTile<VEC, NC, G> ta, tb;
+  issue(ta);
+  for (int s = 0; s < ntiles; s += 2) {
+    if (s + 1 < ntiles) issue(tb);
+    consume(ta);
+    if (s + 1 >= ntiles) break;
+    if (s + 2 < ntiles) issue(ta);
+    consume(tb);
+  }
+  // rows beyond U_b carry stale LDS bytes; every reader masks them out
+  __syncthreads();
+  float4* out = w.rec + (size_t)(b * gm.maxT + t0) * maxU1;
+  for (int i = threadIdx.x; i < rows_blk; i += kRowBlock) out[i] = recs[i];
 }
 
 // ---------------------------------------------------------------------------
 // k_sweep: alpha (even blocks) and beta (odd blocks) anti-diagonal sweeps.
 // One wavefront per (utterance, direction); lane l owns the K lattice columns
-// u = l*K .. l*K+K-1, so one cross-lane shift per diagonal is the only
-// communication and no barrier or LDS traffic sits on the dependent chain.
+// u = l*K .. l*K+K-1, so one cross-lane shift (DPP, no LDS) per diagonal is the
+// only communication and no barrier sits on the dependent chain.  Cells
+// outside the lattice are handled by masking the log-probs that lead into or
+// out of them to "log 0": their alpha/beta then evaluate to ~-1e30 by
+// themselves.  The log-prob rows of the next P diagonals are kept in flight in
+// a register ring.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double log2_add(double p, double q) {
   const double mx = fmax(p, q);
@@ -278,45 +352,54 @@ __device__ __forceinline__ double log2_add(double p, double q) {
   return mx + (double)fast_log2(1.0f + fast_exp2(df));
 }
 
+// lane i receives lane i-1's value; lane 0 receives `fill`
+__device__ __forceinline__ double lane_shift_up(double v, double fill) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// lane i receives lane i+1's value; lane 63 receives `fill`
+__device__ __forceinline__ double lane_shift_down(double v, double fill) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Log-probs {blank, label} of the lattice cells (d-u, u) for this lane's K columns, "log 0" where the cell
+// (or its label move) does not exist.  Records are in [t][u] order, so the lanes of a diagonal read with a
+// stride of maxU1-1 records; the rows stay in L1 for the 8 diagonals that share a cache line.
 template <int K>
-__device__ __forceinline__ void load_lp_row(const float* base, int row, int U1s, int u0, float (&out)[K]) {
-  if (u0 < U1s) {
-    const float* p = base + (size_t)row * U1s + u0;
-    if constexpr (K == 1) {
-      out[0] = p[0];
-    } else if constexpr (K == 2) {
-      const float2 q = *reinterpret_cast<const float2*>(p);
-      out[0] = q.x; out[1] = q.y;
-    } else {
+__device__ __forceinline__ void load_lp_diag(const float4* rec, int d, int maxU1, int u0, const int (&lo)[K],
+                                             const int (&hi)[K], const int (&hil)[K], float (&pb)[K], float (&pl)[K]) {
 #pragma unroll
-      for (int i = 0; i < K; i += 4) {
-        const float4 q = *reinterpret_cast<const float4*>(p + i);
-        out[i] = q.x; out[i + 1] = q.y; out[i + 2] = q.z; out[i + 3] = q.w;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < K; ++i) out[i] = 0.f;
+  for (int i = 0; i < K; ++i) {
+    const int u = u0 + i;
+    const bool in_b = (d >= lo[i]) & (d <= hi[i]);
+    const bool in_l = (d >= lo[i]) & (d <= hil[i]);
+    const int idx = in_b ? (d - u) * maxU1 + u : 0;
+    const float2 q = *reinterpret_cast<const float2*>(rec + idx);
+    pb[i] = in_b ? q.x : kNegF;
+    pl[i] = in_l ? q.y : kNegF;
   }
 }
 
 template <int K>
 __device__ __forceinline__ void store_row(double* base, int row, int U1s, int u0, const double (&v)[K]) {
-  if (u0 < U1s) {
-    double* p = base + (size_t)row * U1s + u0;
-    if constexpr (K == 1) {
-      p[0] = v[0];
-    } else {
+  double* p = base + (size_t)row * U1s + u0;
+  if constexpr (K == 1) {
+    p[0] = v[0];
+  } else {
 #pragma unroll
-      for (int i = 0; i < K; i += 2) *reinterpret_cast<double2*>(p + i) = make_double2(v[i], v[i + 1]);
-    }
+    for (int i = 0; i < K; i += 2) *reinterpret_cast<double2*>(p + i) = make_double2(v[i], v[i + 1]);
   }
 }
 
 template <int K>
 __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, const int32_t* __restrict__ in_len,
                                               const int32_t* __restrict__ lab_len, int B, int maxT, int maxU1) {
-  constexpr int P = 4;  // diagonals of log-probs prefetched ahead of the dependent chain
+  constexpr int P = 4;  // diagonals of log-probs kept in flight ahead of the dependent chain
   const int b = blockIdx.x >> 1;
   const int dir = blockIdx.x & 1;
   const int lane = threadIdx.x;
@@ -324,7 +407,7 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
   const bool ok = (Traw >= 1) & (Traw <= maxT) & (Uraw >= 0) & (Uraw <= maxU1 - 1);
   if (!ok) {
     if (lane == 0) {
-      atomicOr(w.status, RNNT_MI355X_FLAG_BAD_LENGTH);
+      atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LENGTH);
       w.ll[dir * B + b] = 0.0;
       if (dir == 0) costs[b] = __builtin_nanf("");
     }
@@ -333,21 +416,19 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
   const int T = Traw, U = Uraw;
   const int U1s = w.U1s;
   const size_t plane = (size_t)b * w.D * U1s;
-  const float* lpb = w.lpb + plane;
-  const float* lpl = w.lpl + plane;
+  const float4* rec = w.rec + (size_t)b * maxT * maxU1;
   const int u0 = lane * K;
   const int dlast = T - 1 + U;
 
-  // per-column validity window: cell (d-u, u) exists iff u <= U and lo <= d <= hi
-  int lo[K], hi[K];
+  // cell (d-u, u) is in the lattice iff lo <= d <= hi; it has a label move iff also d <= hil
+  int lo[K], hi[K], hil[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const int u = u0 + i;
     lo[i] = u;
-    hi[i] = (u <= U) ? u + T - 1 : -1;  // empty window for columns beyond U
+    hi[i] = (u <= U) ? u + T - 1 : -1;
+    hil[i] = (u < U) ? u + T - 1 : -1;
   }
-
-  float pb[P][K], pl[P][K];
 
   if (dir == 0) {
     double* alpha = w.alpha + plane;
@@ -355,89 +436,80 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
 #pragma unroll
     for (int i = 0; i < K; ++i) a[i] = (u0 + i == 0) ? 0.0 : kNeg;
     store_row<K>(alpha, 0, U1s, u0, a);
+    // one diagonal: a <- alpha(d) from alpha(d-1) and the (masked) log-probs of diagonal d-1
+    auto step = [&](int d, const float (&pb)[K], const float (&pl)[K]) {
+      double el[K];
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int row = min(p, dlast);
-      load_lp_row<K>(lpb, row, U1s, u0, pb[p]);
-      load_lp_row<K>(lpl, row, U1s, u0, pl[p]);
+      for (int i = 0; i < K; ++i) el[i] = a[i] + (double)pl[i];
+      const double from_left = lane_shift_up(el[K - 1], kNeg);
+#pragma unroll
+      for (int i = 0; i < K; ++i) a[i] = log2_add(a[i] + (double)pb[i], (i == 0) ? from_left : el[i - 1]);
+      store_row<K>(alpha, d, U1s, u0, a);
+    };
+    int d = 1;
+    // remainder first, so that the pipelined loop below runs whole groups of P
+    for (const int rem = dlast % P; d <= rem; ++d) {
+      float pb[K], pl[K];
+      load_lp_diag<K>(rec, d - 1, maxU1, u0, lo, hi, hil, pb, pl);
+      step(d, pb, pl);
     }
-    for (int d0 = 1; d0 <= dlast; d0 += P) {
+    if (d <= dlast) {
+      float pb[P][K], pl[P][K];
 #pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int d = d0 + p;
-        if (d <= dlast) {
-          double eb[K], el[K];
+      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec, d - 1 + p, maxU1, u0, lo, hi, hil, pb[p], pl[p]);
+      for (; d <= dlast; d += P) {
 #pragma unroll
-          for (int i = 0; i < K; ++i) {
-            const bool src_ok = (d - 1 >= lo[i]) & (d - 1 <= hi[i]);
-            eb[i] = src_ok ? a[i] + (double)pb[p][i] : kNeg;
-            el[i] = (src_ok & (u0 + i < U)) ? a[i] + (double)pl[p][i] : kNeg;
-          }
-          double from_left = __shfl_up(el[K - 1], 1, 64);
-          if (lane == 0) from_left = kNeg;
-#pragma unroll
-          for (int i = 0; i < K; ++i) {
-            const double left = (i == 0) ? from_left : el[i - 1];
-            const bool tgt_ok = (d >= lo[i]) & (d <= hi[i]);
-            a[i] = tgt_ok ? log2_add(eb[i], left) : kNeg;
-          }
-          store_row<K>(alpha, d, U1s, u0, a);
-          const int nrow = min(d - 1 + P, dlast);
-          load_lp_row<K>(lpb, nrow, U1s, u0, pb[p]);
-          load_lp_row<K>(lpl, nrow, U1s, u0, pl[p]);
+        for (int p = 0; p < P; ++p) {
+          step(d + p, pb[p], pl[p]);
+          // past the last diagonal every cell is masked, so the refill needs no clamp
+          load_lp_diag<K>(rec, d + p - 1 + P, maxU1, u0, lo, hi, hil, pb[p], pl[p]);
+          __builtin_amdgcn_sched_barrier(0);  // keep the refill P diagonals ahead of its use
         }
       }
     }
-    // log2-likelihood = alpha(T-1,U) + lpb(T-1,U): the column-U value of the last diagonal
+    // log2-likelihood = alpha(T-1,U) + log2 P(blank | T-1,U): column U of the last diagonal
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       if (u0 + i == U) {
-        const double ll2 = a[i] + (double)lpb[(size_t)dlast * U1s + U];
+        const double ll2 = a[i] + (double)rec[(size_t)(T - 1) * maxU1 + U].x;
         w.ll[b] = ll2;
         costs[b] = (float)(-ll2 * kLn2);
       }
     }
   } else {
     double* beta = w.beta + plane;
+    // virtual diagonal dlast+1: beta(T,U) = log 1, everything else log 0
     double bt[K];
-    {
-      float last[K];
-      load_lp_row<K>(lpb, dlast, U1s, u0, last);
 #pragma unroll
-      for (int i = 0; i < K; ++i) bt[i] = (u0 + i == U) ? (double)last[i] : kNeg;
+    for (int i = 0; i < K; ++i) bt[i] = (u0 + i == U) ? 0.0 : kNeg;
+    // one diagonal: bt <- beta(d) from beta(d+1) and the (masked) log-probs of diagonal d
+    auto step = [&](int d, const float (&pb)[K], const float (&pl)[K]) {
+      const double from_right = lane_shift_down(bt[0], kNeg);
+      double nb[K];
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+        nb[i] = log2_add(bt[i] + (double)pb[i], ((i == K - 1) ? from_right : bt[i + 1]) + (double)pl[i]);
+#pragma unroll
+      for (int i = 0; i < K; ++i) bt[i] = nb[i];
+      store_row<K>(beta, d, U1s, u0, bt);
+    };
+    int d = dlast;
+    for (int rem = (dlast + 1) % P; rem > 0; --rem, --d) {
+      float pb[K], pl[K];
+      load_lp_diag<K>(rec, d, maxU1, u0, lo, hi, hil, pb, pl);
+      step(d, pb, pl);
     }
-    store_row<K>(beta, dlast, U1s, u0, bt);
+    if (d >= 0) {
+      float pb[P][K], pl[P][K];
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int row = max(dlast - 1 - p, 0);
-      load_lp_row<K>(lpb, row, U1s, u0, pb[p]);
-      load_lp_row<K>(lpl, row, U1s, u0, pl[p]);
-    }
-    for (int d0 = dlast - 1; d0 >= 0; d0 -= P) {
+      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec, d - p, maxU1, u0, lo, hi, hil, pb[p], pl[p]);
+      for (; d >= 0; d -= P) {
 #pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int d = d0 - p;
-        if (d >= 0) {
-          double from_right = __shfl_down(bt[0], 1, 64);
-          if (lane == 63) from_right = kNeg;
-          double nb[K];
-#pragma unroll
-          for (int i = 0; i < K; ++i) {
-            const int u = u0 + i;
-            const double right = (i == K - 1) ? from_right : bt[i + 1];
-            const bool cell_ok = (d >= lo[i]) & (d <= hi[i]);
-            const bool blank_ok = cell_ok & (d + 1 <= hi[i]);  // t+1 <= T-1
-            const bool label_ok = cell_ok & (u < U);
-            const double tb = blank_ok ? bt[i] + (double)pb[p][i] : kNeg;
-            const double tl = label_ok ? right + (double)pl[p][i] : kNeg;
-            nb[i] = cell_ok ? log2_add(tb, tl) : kNeg;
-          }
-#pragma unroll
-          for (int i = 0; i < K; ++i) bt[i] = nb[i];
-          store_row<K>(beta, d, U1s, u0, bt);
-          const int nrow = max(d - P, 0);
-          load_lp_row<K>(lpb, nrow, U1s, u0, pb[p]);
-          load_lp_row<K>(lpl, nrow, U1s, u0, pl[p]);
+        for (int p = 0; p < P; ++p) {
+          step(d - p, pb[p], pl[p]);
+          // below diagonal 0 every cell is masked (d < lo), so the refill needs no clamp
+          load_lp_diag<K>(rec, d - p - P, maxU1, u0, lo, hi, hil, pb[p], pl[p]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -449,134 +521,185 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
 // k_grad: gradient w.r.t. the logits, written over them (or to `grad`).
 //   dx[v] = s * ( 2^(y[v] + c2) - [v==blank] * pb - [v==label] * pl ),
 //   y = x*log2(e), c2 = alpha+beta-ll - lse   (all base-2 logs)
-// Rows are visited in the reverse of k_lse's order so that the rows k_lse read
-// last (still in the memory-side cache) are re-read first.
+// Same block/tile decomposition and two-deep pipeline as k_lse.  Blocks are
+// taken in the reverse of k_lse's order so that the rows k_lse read last
+// (still in the memory-side cache) are re-read first.  Rows that hold no
+// lattice cell are zero-filled without being read.
 // ---------------------------------------------------------------------------
+template <int VEC, int NC, int G>
+struct GradTile {
+  float v[G][NC][VEC];
+  double a[G], be[G], be_t[G], be_u[G];  // alpha(t,u), beta(t,u), beta(t+1,u), beta(t,u+1)  (pass 0 only)
+  float4 rec[G];  // {lpb, lpl, lse, -}
+  int lab[G];
+  int flags[G];  // 1 row inside the block, 2 lattice cell, 4 t < T-1, 8 u == U, 16 u < U
+  int rho[G];
+  int pass;
+};
+
 template <int VEC, int L, int NC, int G>
 __global__ __launch_bounds__(kRowBlock) void k_grad(const float* x, float* grad, const int32_t* __restrict__ labels,
                                                     const int32_t* __restrict__ in_len,
-                                                    const int32_t* __restrict__ lab_len, int B, int maxT, int maxU1,
-                                                    int V, int blank, const float* __restrict__ grad_scale, Ws w,
-                                                    long long nit) {
+                                                    const int32_t* __restrict__ lab_len,
+                                                    const float* __restrict__ grad_scale, RowGeom gm, Ws w) {
   constexpr int R = 64 / L;
-  const int lane = threadIdx.x & 63;
-  const int j = lane % L;
-  const int r = lane / L;
-  const long long wave = (long long)blockIdx.x * (kRowBlock / 64) + (threadIdx.x >> 6);
-  const long long nwaves = (long long)gridDim.x * (kRowBlock / 64);
+  constexpr int S = kRowWaves * G * R;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane % L, r = lane / L;
+  const int bid = gm.nblocks - 1 - (int)blockIdx.x;
+  const int b = bid / gm.nTB;
+  const int t0 = (bid - b * gm.nTB) * gm.TT;
+  int T, U;
+  utt_dims(in_len, lab_len, b, gm.maxT, gm.maxU1, T, U);
+  const int V = gm.V, blank = gm.blank, maxU1 = gm.maxU1, npass = gm.npass;
+  const int rows_blk = (min(t0 + gm.TT, gm.maxT) - t0) * maxU1;  // includes frames >= T_b: they are zero-filled
+  const int ntiles = ((rows_blk + S - 1) / S) * npass;
   const int nchunk = V / VEC;
-  const int cpl = (nchunk + L - 1) / L;
-  const long long total_rows = (long long)B * maxT * maxU1;
-  float sq = 0.f;
+  const int sq = S / maxU1, sr = S % maxU1;
+  const size_t blk_off = (size_t)(b * gm.maxT + t0) * maxU1 * V;
+  const float* xblk = x + blk_off;
+  float* gblk = grad + blk_off;
+  const size_t plane = (size_t)b * w.D * w.U1s;
+  const int U1s = w.U1s;
+  const double ll2 = w.ll[b];
+  const float sc = grad_scale ? grad_scale[b] : 1.f;
 
-  for (long long itf = wave; itf < nit; itf += nwaves) {
-    const long long it = nit - 1 - itf;
-    RowPos pos[G];
-    size_t roff[G];
-    float c2[G], pb[G], pl[G], sc[G];
-    int lab[G];
+  RowCursor<G> cur;
+  cur.init(wv * G * R + r, R, maxU1);
+
+  float c2[G], pb[G], pl[G];
+  int lab[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) { c2[g] = 0.f; pb[g] = 0.f; pl[g] = 0.f; lab[g] = -1; }
+  float sqsum = 0.f;
+
+  auto issue = [&](GradTile<VEC, NC, G>& tl) {
+    tl.pass = cur.pass;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const long long row = (it * G + g) * R + r;
-      pos[g] = decode_row(row, total_rows, maxT, maxU1, in_len, lab_len);
-      roff[g] = (size_t)(pos[g].in_range ? row : 0) * (size_t)V;
-      c2[g] = 0.f; pb[g] = 0.f; pl[g] = 0.f; sc[g] = 0.f; lab[g] = -1;
-      if (pos[g].valid) {
-        const int t = pos[g].t, u = pos[g].u, T = pos[g].T, U = pos[g].U;
-        const size_t ci = ((size_t)pos[g].b * w.D + (t + u)) * w.U1s + u;
-        const double a = w.alpha[ci];
-        const double ll2 = w.ll[pos[g].b];
-        const double a_ll = a - ll2;
-        const float lse2 = w.lse[ci];
-        const float lpb2 = w.lpb[ci];
-        sc[g] = grad_scale ? grad_scale[pos[g].b] : 1.f;
-        c2[g] = (float)(a_ll + w.beta[ci]) - lse2;
-        if (t < T - 1) {
-          pb[g] = fast_exp2((float)(a_ll + w.beta[ci + w.U1s]) + lpb2);
-        } else if (u == U) {
-          pb[g] = fast_exp2((float)a_ll + lpb2);
-        }
+      const int t = t0 + cur.tt[g], u = cur.uu[g];
+      const bool in_blk = cur.rho[g] < rows_blk;
+      const bool valid = in_blk & (t < T) & (u <= U);
+      tl.flags[g] = (in_blk ? 1 : 0) | (valid ? 2 : 0) | ((valid & (t < T - 1)) ? 4 : 0) |
+                    ((valid & (u == U)) ? 8 : 0) | ((valid & (u < U)) ? 16 : 0);
+      tl.rho[g] = in_blk ? cur.rho[g] : 0;
+      tl.lab[g] = -1;
+      tl.a[g] = 0.0; tl.be[g] = 0.0; tl.be_t[g] = 0.0; tl.be_u[g] = 0.0;
+      tl.rec[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cur.pass == 0 && valid) {
+        const size_t ci = plane + (size_t)(t + u) * U1s + u;
+        tl.a[g] = w.alpha[ci];
+        tl.be[g] = w.beta[ci];
+        tl.rec[g] = w.rec[((size_t)b * gm.maxT + t) * maxU1 + u];
+        if (t < T - 1) tl.be_t[g] = w.beta[ci + U1s];
         if (u < U) {
-          int l = labels[(size_t)pos[g].b * (maxU1 - 1) + u];
-          l = (l < 0 || l >= V) ? 0 : l;
-          lab[g] = l;
-          pl[g] = fast_exp2((float)(a_ll + w.beta[ci + w.U1s + 1]) + w.lpl[ci]);
+          tl.be_u[g] = w.beta[ci + U1s + 1];
+          const int l = labels[(size_t)b * (maxU1 - 1) + u];
+          tl.lab[g] = (l < 0 || l >= V) ? 0 : l;
+        }
+      }
+      const float* rp = xblk + (size_t)tl.rho[g] * V;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int c = j + L * (cur.pass * NC + i);
+        if (valid && c < nchunk) {
+          load_vec<VEC>(rp + (size_t)c * VEC, tl.v[g][i]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) tl.v[g][i][q] = 0.f;
         }
       }
     }
-    for (int k0 = 0; k0 < cpl; k0 += NC) {
-      float v[G][NC][VEC];
+    cur.advance(npass, S, sq, sr, maxU1);
+  };
+
+  auto consume = [&](const GradTile<VEC, NC, G>& tl) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
+    for (int g = 0; g < G; ++g) {
+      const int f = tl.flags[g];
+      if (tl.pass == 0) {
+        const double a_ll = tl.a[g] - ll2;
+        c2[g] = (float)(a_ll + tl.be[g]) - tl.rec[g].z;
+        float e_b = -INFINITY;  // 2^-inf = 0: no blank term
+        if (f & 4) e_b = (float)(a_ll + tl.be_t[g]) + tl.rec[g].x;
+        else if (f & 8) e_b = (float)a_ll + tl.rec[g].x;
+        pb[g] = (f & 2) ? fast_exp2(e_b) : 0.f;
+        pl[g] = (f & 16) ? fast_exp2((float)(a_ll + tl.be_u[g]) + tl.rec[g].y) : 0.f;
+        lab[g] = tl.lab[g];
+      }
+      float* gp = gblk + (size_t)tl.rho[g] * V;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-          const int c = j + L * (k0 + i);
-          if (pos[g].valid && c < nchunk) {
-            load_vec<VEC>(x + roff[g] + (size_t)c * VEC, v[g][i]);
+      for (int i = 0; i < NC; ++i) {
+        const int c = j + L * (tl.pass * NC + i);
+        if ((f & 1) && c < nchunk) {
+          float o[VEC];
+          if (f & 2) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+              const int e = c * VEC + q;
+              float gv = fast_exp2(__builtin_fmaf(tl.v[g][i][q], kLog2e, c2[g]));
+              gv -= (e == blank) ? pb[g] : 0.f;
+              gv -= (e == lab[g]) ? pl[g] : 0.f;
+              gv *= sc;
+              sqsum = __builtin_fmaf(gv, gv, sqsum);
+              o[q] = gv;
+            }
           } else {
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) v[g][i][q] = 0.f;
+            for (int q = 0; q < VEC; ++q) o[q] = 0.f;
           }
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-          const int c = j + L * (k0 + i);
-          if (pos[g].in_range && c < nchunk) {
-            float o[VEC];
-            if (pos[g].valid) {
-#pragma unroll
-              for (int q = 0; q < VEC; ++q) {
-                const int e = c * VEC + q;
-                float gv = fast_exp2(__builtin_fmaf(v[g][i][q], kLog2e, c2[g]));
-                gv -= (e == blank) ? pb[g] : 0.f;
-                gv -= (e == lab[g]) ? pl[g] : 0.f;
-                gv *= sc[g];
-                sq = __builtin_fmaf(gv, gv, sq);
-                o[q] = gv;
-              }
-            } else {
-#pragma unroll
-              for (int q = 0; q < VEC; ++q) o[q] = 0.f;
-            }
-            store_vec<VEC>(grad + roff[g] + (size_t)c * VEC, o);
-          }
+          store_vec<VEC>(gp + (size_t)c * VEC, o);
         }
       }
     }
+  };
+
+  GradTile<VEC, NC, G> ta, tb;
+  issue(ta);
+  for (int s = 0; s < ntiles; s += 2) {
+    if (s + 1 < ntiles) issue(tb);
+    consume(ta);
+    if (s + 1 >= ntiles) break;
+    if (s + 2 < ntiles) issue(ta);
+    consume(tb);
   }
-  // per-block sum of squared gradient elements (deterministic: one slot per block)
-  __shared__ float red[kRowBlock / 64];
-  sq = group_sum<64>(sq);
-  if (lane == 0) red[threadIdx.x >> 6] = sq;
+
+  // per-block sum of squared gradient elements (one slot per block: deterministic)
+  __shared__ float red[kRowWaves];
+  sqsum = group_sum<64>(sqsum);
+  if (lane == 0) red[wv] = sqsum;
   __syncthreads();
   if (threadIdx.x == 0) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kRowBlock / 64; ++i) s += red[i];
-    w.partial[blockIdx.x] = s;
+    for (int i = 0; i < kRowWaves; ++i) s += red[i];
+    w.partial[bid] = s;
   }
 }
 
-__global__ __launch_bounds__(256) void k_init(Ws w) {
-  if (threadIdx.x < kStatusInts) w.status[threadIdx.x] = 0;
-  for (int i = threadIdx.x; i < kMaxRowBlocks; i += 256) w.partial[i] = 0.f;
+__global__ __launch_bounds__(64) void k_init(Ws w, int n_partial) {
+  if (threadIdx.x == 0) {
+    w.hdr->flags = 0;
+    w.hdr->n_partial = n_partial;
+    w.hdr->partial_off = w.partial_off;
+  }
 }
 
 // out2[0] = sum costs, out2[1] = sum of the per-block partials of the last k_grad.
-__global__ __launch_bounds__(256) void k_reduce_scalars(const float* __restrict__ costs, int B, Ws w, int nblocks,
-                                                        double* __restrict__ out2) {
-  __shared__ double sh[2][256];
+__global__ __launch_bounds__(1024) void k_reduce_scalars(const float* __restrict__ costs, int B, const char* ws_base,
+                                                         double* __restrict__ out2) {
+  __shared__ double sh[2][1024];
+  const Header* hdr = reinterpret_cast<const Header*>(ws_base);
+  const float* partial = reinterpret_cast<const float*>(ws_base + hdr->partial_off);
+  const int n = hdr->n_partial;
   double c = 0.0, s = 0.0;
-  for (int i = threadIdx.x; i < B; i += 256) c += (double)costs[i];
-  for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)w.partial[i];
+  for (int i = threadIdx.x; i < B; i += 1024) c += (double)costs[i];
+  for (int i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
   sh[0][threadIdx.x] = c;
   sh[1][threadIdx.x] = s;
   __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if (threadIdx.x < o) {
+  for (int o = 512; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) {
       sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
       sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
     }
@@ -594,44 +717,52 @@ __global__ __launch_bounds__(256) void k_reduce_scalars(const float* __restrict_
 
 struct RowCfg {
   int vec, L, nc, g;
-  long long nit;
-  int blocks;
+  RowGeom gm;
 };
 
-RowCfg pick_row_cfg(int B, int maxT, int maxU1, int V, const void* p0, const void* p1) {
+RowCfg pick_row_cfg(int B, int maxT, int maxU1, int V, int blank, const void* p0, const void* p1) {
   RowCfg c;
   const uintptr_t a = reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1);
   c.vec = (V % 4 == 0 && a % 16 == 0) ? 4 : (V % 2 == 0 && a % 8 == 0) ? 2 : 1;
   const int nchunk = V / c.vec;
   c.L = 8;
   while (c.L < 64 && c.L < nchunk) c.L <<= 1;
-  const int cpl = (nchunk + c.L - 1) / c.L;
+  const int cpl = (nchunk + c.L - 1) / c.L;  // chunks per lane per row
   c.nc = cpl >= 3 ? 4 : cpl;
   c.g = 4 / c.nc;
-  const long long rows = (long long)B * maxT * maxU1;
-  const long long rows_per_it = (long long)(64 / c.L) * c.g;
-  c.nit = (rows + rows_per_it - 1) / rows_per_it;
-  const long long want = (c.nit + (kRowBlock / 64) - 1) / (kRowBlock / 64);
-  c.blocks = (int)(want < kMaxRowBlocks ? want : kMaxRowBlocks);
-  if (c.blocks < 1) c.blocks = 1;
+  const int rows_per_iter = kRowWaves * c.g * (64 / c.L);
+  // frames per block: about 24 tiles per wave, so that the pipeline fill/drain is amortised
+  int TT = (24 * rows_per_iter + maxU1 - 1) / maxU1;
+  while (TT > 1 && TT * maxU1 > 2048) --TT;  // the block's records are staged in LDS (<= 32 KiB)
+  if (TT < 1) TT = 1;
+  if (TT > maxT) TT = maxT;
+  c.gm.maxT = maxT;
+  c.gm.maxU1 = maxU1;
+  c.gm.V = V;
+  c.gm.blank = blank;
+  c.gm.TT = TT;
+  c.gm.nTB = (maxT + TT - 1) / TT;
+  c.gm.npass = (cpl + c.nc - 1) / c.nc;
+  c.gm.nblocks = B * c.gm.nTB;
   return c;
 }
 
-#define RNNT_DISPATCH_LNG(KERNEL, VEC, cfg, ...)                                                              \
-  do {                                                                                                        \
-    if ((cfg).L == 64 && (cfg).nc == 4) KERNEL<VEC, 64, 4, 1><<<(cfg).blocks, kRowBlock, 0, st>>>(__VA_ARGS__); \
-    else if ((cfg).L == 64 && (cfg).nc == 2) KERNEL<VEC, 64, 2, 2><<<(cfg).blocks, kRowBlock, 0, st>>>(__VA_ARGS__); \
-    else if ((cfg).L == 64) KERNEL<VEC, 64, 1, 4><<<(cfg).blocks, kRowBlock, 0, st>>>(__VA_ARGS__);           \
-    else if ((cfg).L == 32) KERNEL<VEC, 32, 1, 4><<<(cfg).blocks, kRowBlock, 0, st>>>(__VA_ARGS__);           \
-    else if ((cfg).L == 16) KERNEL<VEC, 16, 1, 4><<<(cfg).blocks, kRowBlock, 0, st>>>(__VA_ARGS__);           \
-    else KERNEL<VEC, 8, 1, 4><<<(cfg).blocks, kRowBlock, 0, st>>>(__VA_ARGS__);                               \
+#define RNNT_DISPATCH_LNG(KERNEL, VEC, cfg, LDS, ...)                                                     \
+  do {                                                                                                    \
+    const dim3 grid_((cfg).gm.nblocks), blk_(kRowBlock);                                                  \
+    if ((cfg).L == 64 && (cfg).nc == 4) KERNEL<VEC, 64, 4, 1><<<grid_, blk_, LDS, st>>>(__VA_ARGS__);      \
+    else if ((cfg).L == 64 && (cfg).nc == 2) KERNEL<VEC, 64, 2, 2><<<grid_, blk_, LDS, st>>>(__VA_ARGS__); \
+    else if ((cfg).L == 64) KERNEL<VEC, 64, 1, 4><<<grid_, blk_, LDS, st>>>(__VA_ARGS__);                  \
+    else if ((cfg).L == 32) KERNEL<VEC, 32, 1, 4><<<grid_, blk_, LDS, st>>>(__VA_ARGS__);                  \
+    else if ((cfg).L == 16) KERNEL<VEC, 16, 1, 4><<<grid_, blk_, LDS, st>>>(__VA_ARGS__);                  \
+    else KERNEL<VEC, 8, 1, 4><<<grid_, blk_, LDS, st>>>(__VA_ARGS__);                                      \
   } while (0)
 
-#define RNNT_DISPATCH(KERNEL, cfg, ...)                                  \
-  do {                                                                   \
-    if ((cfg).vec == 4) RNNT_DISPATCH_LNG(KERNEL, 4, cfg, __VA_ARGS__);  \
-    else if ((cfg).vec == 2) RNNT_DISPATCH_LNG(KERNEL, 2, cfg, __VA_ARGS__); \
-    else RNNT_DISPATCH_LNG(KERNEL, 1, cfg, __VA_ARGS__);                 \
+#define RNNT_DISPATCH(KERNEL, cfg, LDS, ...)                                      \
+  do {                                                                            \
+    if ((cfg).vec == 4) RNNT_DISPATCH_LNG(KERNEL, 4, cfg, LDS, __VA_ARGS__);      \
+    else if ((cfg).vec == 2) RNNT_DISPATCH_LNG(KERNEL, 2, cfg, LDS, __VA_ARGS__); \
+    else RNNT_DISPATCH_LNG(KERNEL, 1, cfg, LDS, __VA_ARGS__);                     \
   } while (0)
 
 int check_shape(int B, int maxT, int maxU1, int V, int blank) {
@@ -648,15 +779,21 @@ int launch_forward(const float* logits, const int32_t* labels, const int32_t* in
                    int maxT, int maxU1, int V, int blank, float* costs, void* workspace, hipStream_t st) {
   Ws w;
   ws_layout(workspace, B, maxT, maxU1, &w);
-  k_init<<<1, 256, 0, st>>>(w);
-  const RowCfg cfg = pick_row_cfg(B, maxT, maxU1, V, logits, logits);
-  RNNT_DISPATCH(k_lse, cfg, logits, labels, in_len, lab_len, B, maxT, maxU1, V, blank, w, cfg.nit);
+  const RowCfg cfg = pick_row_cfg(B, maxT, maxU1, V, blank, logits, logits);
+  k_init<<<1, 64, 0, st>>>(w, 0);
+  RNNT_DISPATCH(k_lse, cfg, sizeof(float4) * (size_t)cfg.gm.TT * maxU1, logits, labels, in_len, lab_len, cfg.gm, w);
   const int grid = 2 * B;
-  if (maxU1 <= 64) k_sweep<1><<<grid, 64, 0, st>>>(w, costs, in_len, lab_len, B, maxT, maxU1);
-  else if (maxU1 <= 128) k_sweep<2><<<grid, 64, 0, st>>>(w, costs, in_len, lab_len, B, maxT, maxU1);
-  else if (maxU1 <= 256) k_sweep<4><<<grid, 64, 0, st>>>(w, costs, in_len, lab_len, B, maxT, maxU1);
-  else k_sweep<8><<<grid, 64, 0, st>>>(w, costs, in_len, lab_len, B, maxT, maxU1);
+  switch (sweep_cols_per_lane(maxU1)) {
+    case 1: k_sweep<1><<<grid, 64, 0, st>>>(w, costs, in_len, lab_len, B, maxT, maxU1); break;
+    case 2: k_sweep<2><<<grid, 64, 0, st>>>(w, costs, in_len, lab_len, B, maxT, maxU1); break;
+    case 4: k_sweep<4><<<grid, 64, 0, st>>>(w, costs, in_len, lab_len, B, maxT, maxU1); break;
+    default: k_sweep<8><<<grid, 64, 0, st>>>(w, costs, in_len, lab_len, B, maxT, maxU1); break;
+  }
   return launch_status();
+}
+
+__global__ __launch_bounds__(64) void k_set_partial_count(Ws w, int n_partial) {
+  if (threadIdx.x == 0) w.hdr->n_partial = n_partial;
 }
 
 int launch_backward(const float* logits, float* grad, const int32_t* labels, const int32_t* in_len,
@@ -664,8 +801,9 @@ int launch_backward(const float* logits, float* grad, const int32_t* labels, con
                     void* workspace, hipStream_t st) {
   Ws w;
   ws_layout(workspace, B, maxT, maxU1, &w);
-  const RowCfg cfg = pick_row_cfg(B, maxT, maxU1, V, logits, grad);
-  RNNT_DISPATCH(k_grad, cfg, logits, grad, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale, w, cfg.nit);
+  const RowCfg cfg = pick_row_cfg(B, maxT, maxU1, V, blank, logits, grad);
+  RNNT_DISPATCH(k_grad, cfg, 0, logits, grad, labels, in_len, lab_len, grad_scale, cfg.gm, w);
+  k_set_partial_count<<<1, 64, 0, st>>>(w, cfg.gm.nblocks);
   return launch_status();
 }
 
@@ -735,10 +873,8 @@ int rnnt_mi355x_loss_grad(float* logits_inout, const int32_t* labels, const int3
 
 int rnnt_mi355x_reduce_scalars(const float* costs, int B, void* workspace, double* out2, void* hip_stream) {
   if (!costs || !workspace || !out2 || B < 1) return RNNT_MI355X_INVALID_VALUE;
-  // only the leading (shape-independent) part of the layout is touched here
-  Ws w;
-  ws_layout(workspace, B, 1, 1, &w);
-  k_reduce_scalars<<<1, 256, 0, static_cast<hipStream_t>(hip_stream)>>>(costs, B, w, kMaxRowBlocks, out2);
+  k_reduce_scalars<<<1, 1024, 0, static_cast<hipStream_t>(hip_stream)>>>(costs, B, static_cast<const char*>(workspace),
+                                                                        out2);
   return launch_status();
 }
 
