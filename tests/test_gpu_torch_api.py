@@ -1,0 +1,152 @@
+"""The reference-shaped Python surface on the GPU: rnnt_loss autograd, the two
+lambda functions (reference rnnt/base/util.py:53-74, 93-117), the module, input
+validation, and a sharded run compared with the unsharded one."""
+import numpy as np
+import pytest
+import torch
+
+import rnnt_amd
+from oracle import rnnt_oracle as orc
+from rnnt_amd.loss import reduce_scalars, _workspace
+from tests.hip_runner import make_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+COST_RTOL = 1e-5
+GRAD_ATOL = 1e-4
+
+
+def test_autograd_matches_oracle_and_leaves_acts_intact():
+    x, lab, il, ll = make_batch(4, 21, 8, 62, 39, seed=3)
+    acts = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    costs = rnnt_amd.rnnt_loss(acts, torch.from_numpy(lab), torch.from_numpy(il), torch.from_numpy(ll), 39)
+    w = torch.tensor([0.5, 1.0, 2.0, 0.25], device=DEV)
+    (costs * w).sum().backward()
+    co, go = orc.rnnt_loss_and_grad(x, lab, il, ll, 39, w.cpu().numpy())
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+    assert np.abs(acts.grad.cpu().numpy() - go).max() < GRAD_ATOL
+    assert torch.equal(acts.detach().cpu(), torch.from_numpy(x))
+
+
+def test_keras_mean_loss_gives_one_over_b_scale():
+    """loss = mean_b cost_b, the identity-loss reduction of reference keras_model.py:215-217."""
+    x, lab, il, ll = make_batch(3, 10, 4, 16, 15, seed=8)
+    acts = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    loss = rnnt_amd.RNNTLoss(blank_label=15)(acts, torch.from_numpy(lab), torch.from_numpy(il), torch.from_numpy(ll))
+    loss.backward()
+    co, go = orc.rnnt_loss_and_grad(x, lab, il, ll, 15, np.full(3, 1 / 3))
+    np.testing.assert_allclose(loss.item(), co.mean(), rtol=COST_RTOL)
+    assert np.abs(acts.grad.cpu().numpy() - go).max() < GRAD_ATOL
+
+
+def test_rnnt_lambda_func_additive_joint():
+    rng = np.random.default_rng(5)
+    B, T0, U, V = 3, 14, 5, 40
+    yt = rng.standard_normal((B, T0, V)).astype(np.float32)
+    yp = rng.standard_normal((B, U + 1, V)).astype(np.float32)
+    lab = rng.integers(0, V - 1, (B, U)).astype(np.int32)
+    il = np.array([[14], [9], [12]], np.int32)   # [B,1] as the Keras Inputs deliver them
+    ll = np.array([[5], [2], [4]], np.int32)
+    t_yt = torch.from_numpy(yt).to(DEV).requires_grad_(True)
+    t_yp = torch.from_numpy(yp).to(DEV).requires_grad_(True)
+    t_il = torch.from_numpy(il).to(DEV)
+    costs = rnnt_amd.rnnt_lambda_func([t_yt, t_yp, torch.from_numpy(lab).to(DEV), t_il, torch.from_numpy(ll).to(DEV)])
+    assert costs.shape == (B,)
+    costs.mean().backward()
+    co, dt, dp = orc.rnnt_lambda_func(yt, yp, lab, il, ll, blank_label=39, grad_scale=np.full(B, 1 / B))
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+    assert np.abs(t_yt.grad.cpu().numpy() - dt).max() < GRAD_ATOL
+    assert np.abs(t_yp.grad.cpu().numpy() - dp).max() < GRAD_ATOL
+    assert not t_yt.grad[:, :2].any()                      # the two cropped frames (util.py:101)
+    assert torch.equal(t_il.cpu(), torch.from_numpy(il))   # caller's lengths are not edited in place
+
+
+def test_rnnt_lambda_func_v2_fc_joint():
+    rng = np.random.default_rng(6)
+    B, T0, U, V = 2, 11, 4, 62
+    a = rng.standard_normal((B, T0, U + 1, V)).astype(np.float32)
+    lab = rng.integers(0, 39, (B, U)).astype(np.int32)
+    il = np.array([[11], [8]], np.int32)
+    ll = np.array([[4], [3]], np.int32)
+    t_a = torch.from_numpy(a).to(DEV).requires_grad_(True)
+    costs = rnnt_amd.rnnt_lambda_func_v2([t_a, torch.from_numpy(lab).to(DEV), torch.from_numpy(il).to(DEV), torch.from_numpy(ll).to(DEV)])
+    costs.sum().backward()
+    co, da = orc.rnnt_lambda_func_v2(a, lab, il, ll, blank_label=39)
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+    assert np.abs(t_a.grad.cpu().numpy() - da).max() < GRAD_ATOL
+    assert torch.equal(t_a.detach().cpu(), torch.from_numpy(a))  # the crop is copied, the joint output survives
+
+
+def test_inplace_backward_reuses_the_acts_buffer():
+    x, lab, il, ll = make_batch(2, 9, 4, 32, 31, seed=12)
+    base = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    acts = base * 1.0
+    ptr = acts.data_ptr()
+    costs = rnnt_amd.rnnt_loss(acts, lab, il, ll, 31, inplace=True)
+    costs.sum().backward()
+    _, go = orc.rnnt_loss_and_grad(x, lab, il, ll, 31)
+    assert np.abs(base.grad.cpu().numpy() - go).max() < GRAD_ATOL
+    assert acts.data_ptr() == ptr and np.abs(acts.detach().cpu().numpy() - go).max() < GRAD_ATOL
+
+
+def test_fused_inplace_call_and_scalars():
+    x, lab, il, ll = make_batch(3, 12, 6, 48, 0, seed=13)
+    acts = torch.from_numpy(x).to(DEV)
+    ws = _workspace(3, 12, 7, acts.device)
+    gs = torch.full((3,), 1 / 3)
+    costs = rnnt_amd.rnnt_loss_grad_(acts, lab, il, ll, 0, gs, workspace=ws, check_inputs=True)
+    co, go = orc.rnnt_loss_and_grad(x, lab, il, ll, 0, gs.numpy())
+    np.testing.assert_allclose(costs.cpu().numpy(), co, rtol=COST_RTOL)
+    assert np.abs(acts.cpu().numpy() - go).max() < GRAD_ATOL
+    s = reduce_scalars(costs, ws).cpu().numpy()
+    np.testing.assert_allclose(s, [co.sum(), (go ** 2).sum()], rtol=1e-4)
+
+
+def test_malformed_inputs_raise():
+    x, lab, il, ll = make_batch(2, 6, 3, 8, 7, seed=1, ragged=False)
+    acts = torch.from_numpy(x).to(DEV)
+    with pytest.raises(ValueError):
+        rnnt_amd.rnnt_loss(acts, lab, np.array([7, 6]), ll, 7)                # host lengths: checked on the host
+    with pytest.raises(ValueError):
+        rnnt_amd.rnnt_loss(acts, lab, torch.tensor([7, 6], device=DEV), ll, 7)  # device lengths: checked on the device
+    bad = lab.copy()
+    bad[0, 0] = 9
+    with pytest.raises(ValueError):
+        rnnt_amd.rnnt_loss(acts, bad, il, ll, 7)
+    with pytest.raises(ValueError):
+        rnnt_amd.rnnt_loss(acts, lab, il, ll, 8)                               # blank outside [0,V)
+    with pytest.raises(TypeError):
+        rnnt_amd.rnnt_loss(acts.double(), lab, il, ll, 7)
+    with pytest.raises(ValueError):
+        rnnt_amd.rnnt_loss(acts, lab[:, :2], il, ll, 7)
+
+
+def test_sharded_run_equals_unsharded():
+    """Every rank's shard computed one after the other on the one GPU ("fake
+    world"): the all-reduced scalars and the per-utterance results must equal
+    the unsharded run's."""
+    rng = np.random.default_rng(21)
+    B, T, U, V, blank = 7, 40, 12, 62, 39
+    x = rng.standard_normal((B, T, U + 1, V)).astype(np.float32)
+    lab = rng.integers(0, 39, (B, U)).astype(np.int32)
+    il = rng.integers(10, T + 1, B).astype(np.int32)
+    ll = rng.integers(0, U + 1, B).astype(np.int32)
+    full = torch.from_numpy(x).to(DEV)
+    ws = _workspace(B, T, U + 1, full.device)
+    gs = torch.full((B,), 1.0 / B)
+    ref_costs = rnnt_amd.rnnt_loss_grad_(full.clone(), lab, il, ll, blank, gs, workspace=ws)
+    ref_s = reduce_scalars(ref_costs, ws).cpu().numpy()
+    ref_grad = full.clone()
+    rnnt_amd.rnnt_loss_grad_(ref_grad, lab, il, ll, blank, gs)
+    total = np.zeros(2)
+    for world in (2, 3):
+        total[:] = 0
+        for rank in range(world):
+            a, lb, i2, l2, idx = rnnt_amd.shard_batch(torch.from_numpy(x).to(DEV), torch.from_numpy(lab), il, ll, rank, world)
+            w2 = _workspace(len(idx), a.shape[1], a.shape[2], a.device)
+            c = rnnt_amd.rnnt_loss_grad_(a, lb, i2, l2, blank, torch.full((len(idx),), 1.0 / B), workspace=w2)
+            total += reduce_scalars(c, w2).cpu().numpy()
+            for k, i in enumerate(idx):
+                assert torch.equal(c[k], ref_costs[i])
+                assert torch.equal(a[k, : il[i], : ll[i] + 1], ref_grad[i, : il[i], : ll[i] + 1])
+        np.testing.assert_allclose(total, ref_s, rtol=1e-6)
