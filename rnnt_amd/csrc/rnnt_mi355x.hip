@@ -156,17 +156,33 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
   }
 }
 
-template <int L>
-__device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-  for (int o = L / 2; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// All-reduce inside aligned groups of L lanes.  The steps inside a row of 16
+// lanes are DPP operand modifiers (quad swaps, half-row mirror, row mirror:
+// one VALU instruction each, no LDS); only the 16- and 32-lane steps go
+// through the LDS crossbar.  max and + are commutative, so paired lanes end up
+// with bit-identical values.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int L, typename Op>
+__device__ __forceinline__ float group_reduce(float v, Op op) {
+  static_assert(L == 8 || L == 16 || L == 32 || L == 64, "group size");
+  v = op(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = op(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = op(v, dpp_mov<0x141>(v));  // row_half_mirror
+  if constexpr (L >= 16) v = op(v, dpp_mov<0x140>(v));  // row_mirror
+  if constexpr (L >= 32) v = op(v, __shfl_xor(v, 16, 64));
+  if constexpr (L >= 64) v = op(v, __shfl_xor(v, 32, 64));
   return v;
 }
 template <int L>
+__device__ __forceinline__ float group_max(float v) {
+  return group_reduce<L>(v, [](float a, float b) { return fmaxf(a, b); });
+}
+template <int L>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = L / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return group_reduce<L>(v, [](float a, float b) { return a + b; });
 }
 
 // Rows of the current tile owned by this lane, advanced incrementally (no
@@ -730,6 +746,8 @@ RowCfg pick_row_cfg(int B, int maxT, int maxU1, int V, int blank, const void* p0
   const uintptr_t a = reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1);
   c.vec = (V % 4 == 0 && a % 16 == 0) ? 4 : (V % 2 == 0 && a % 8 == 0) ? 2 : 1;
   const int nchunk = V / c.vec;
+  // lanes per row: one vector load of the group covers as much of the row as possible (whole-row contiguous
+  // accesses; partial-line non-temporal stores are slow), between 8 and 64 lanes
   c.L = 8;
   while (c.L < 64 && c.L < nchunk) c.L <<= 1;
   const int cpl = (nchunk + c.L - 1) / c.L;  // chunks per lane per row
