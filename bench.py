@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the RNN-T loss hot path (fused forward + in-place backward).
 
-One "step" = one rnnt_mi355x_forward + rnnt_mi355x_backward_inplace over one
-batch of synthetic logits already resident in HBM (exactly what
-rnnt_mi355x_loss_grad does, split in two calls so that the dominant kernel can
-be timed with events on the launch stream), followed by the reduction of the
-two data-parallel scalars and, for N > 1, their all-reduce over RCCL.
+One "step" = one rnnt_mi355x_loss_grad (fused forward + in-place backward; its
+_events form, so that the gradient kernels are bracketed by events on the
+launch stream) over one batch of synthetic logits already resident in HBM,
+followed by the reduction of the two data-parallel scalars and, for N > 1,
+their all-reduce over RCCL.
 
 Metric: lattice cells per second, whole job (all ranks), where a cell is one
 (b, t, u) with t < T_b and u <= U_b.  Weak scaling: every rank processes its own
@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--ring", type=int, default=0, help="logits buffers to cycle through (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override B (debug)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,13 +110,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    local_rank %= torch.cuda.device_count()  # rehearsals with more ranks than devices share a device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **({"device_id": dev} if args.backend == "nccl" else {}))
 
     from rnnt_amd import _lib
     L = _lib.lib()
@@ -158,15 +160,19 @@ def main():
 
     ev_pairs = []
 
+    def new_event():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)  # materialises the hipEvent_t; the library re-records it
+        return e
+
     def step(buf, timed):
-        rc = L.rnnt_mi355x_forward(_p(buf), _p(labels), _p(il), _p(ll), *meta, _p(costs), _p(ws), sp)
+        e0 = e1 = None
         if timed:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-        rc |= L.rnnt_mi355x_backward_inplace(_p(buf), _p(labels), _p(il), _p(ll), *meta, _p(grad_scale), _p(ws), sp)
+            e0, e1 = new_event(), new_event()
+        rc = L.rnnt_mi355x_loss_grad_events(_p(buf), _p(labels), _p(il), _p(ll), *meta, _p(grad_scale), _p(costs),
+                                            _p(ws), sp, ctypes.c_void_p(e0.cuda_event) if timed else None,
+                                            ctypes.c_void_p(e1.cuda_event) if timed else None)
         if timed:
-            e1.record(stream)
             ev_pairs.append((e0, e1))
         rc |= L.rnnt_mi355x_reduce_scalars(_p(costs), B, _p(ws), _p(scal), sp)
         if rc != 0:

@@ -91,6 +91,15 @@ int rnnt_mi355x_loss_grad(float* logits_inout, const int32_t* labels, const int3
                           int B, int maxT, int maxU1, int V, int blank, const float* grad_scale, float* costs,
                           void* workspace, void* hip_stream);
 
+/* rnnt_mi355x_loss_grad with two optional hipEvent_t handles recorded on
+ * `hip_stream` immediately before and after the gradient-kernel launch (NULL = not recorded).  A measurement aid for callers that want the
+ * gradient pass timed on the launch stream; it has no counterpart in the
+ * reference. */
+int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, const int32_t* in_len,
+                                 const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
+                                 const float* grad_scale, float* costs, void* workspace, void* hip_stream,
+                                 void* ev_grad_begin, void* ev_grad_end);
+
 /* out2[0] = sum_b costs[b], out2[1] = sum of squared gradient elements of the
  * last backward on this workspace (both float64, device memory).  These are
  * the two scalars a data-parallel caller all-reduces: the batch loss of

@@ -107,7 +107,9 @@ struct RowGeom {
   int TT;     // frames per block
   int nTB;    // frame blocks per utterance
   int npass;  // passes of NC chunks per lane over one row
-  int nblocks;
+  int b0;     // first utterance of this launch
+  int nblocks;      // blocks of this launch = (utterances of this launch) * nTB
+  int nblocks_all;  // blocks of the whole batch = B * nTB
 };
 
 // ---------------------------------------------------------------------------
@@ -244,8 +246,9 @@ __global__ __launch_bounds__(kRowBlock) void k_lse(const float* __restrict__ x, 
   constexpr int S = kRowWaves * G * R;  // rows per block iteration
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = lane % L, r = lane / L;
-  const int b = blockIdx.x / gm.nTB;
-  const int t0 = (blockIdx.x - b * gm.nTB) * gm.TT;
+  const int bl = blockIdx.x / gm.nTB;  // utterance within this launch
+  const int b = gm.b0 + bl;
+  const int t0 = (blockIdx.x - bl * gm.nTB) * gm.TT;
   int T, U;
   utt_dims(in_len, lab_len, b, gm.maxT, gm.maxU1, T, U);
   if (t0 >= T) return;  // frames at or beyond T_b hold no lattice cell
@@ -414,9 +417,10 @@ __device__ __forceinline__ void store_row(double* base, int row, int U1s, int u0
 
 template <int K>
 __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, const int32_t* __restrict__ in_len,
-                                              const int32_t* __restrict__ lab_len, int B, int maxT, int maxU1) {
+                                              const int32_t* __restrict__ lab_len, int B, int maxT, int maxU1,
+                                              int b0) {
   constexpr int P = 4;  // diagonals of log-probs kept in flight ahead of the dependent chain
-  const int b = blockIdx.x >> 1;
+  const int b = b0 + (blockIdx.x >> 1);
   const int dir = blockIdx.x & 1;
   const int lane = threadIdx.x;
   const int Traw = in_len[b], Uraw = lab_len[b];
@@ -563,8 +567,9 @@ __global__ __launch_bounds__(kRowBlock) void k_grad(const float* x, float* grad,
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = lane % L, r = lane / L;
   const int bid = gm.nblocks - 1 - (int)blockIdx.x;
-  const int b = bid / gm.nTB;
-  const int t0 = (bid - b * gm.nTB) * gm.TT;
+  const int bl = bid / gm.nTB;  // utterance within this launch
+  const int b = gm.b0 + bl;
+  const int t0 = (bid - bl * gm.nTB) * gm.TT;
   const int V = gm.V, blank = gm.blank, maxU1 = gm.maxU1, npass = gm.npass;
   const int nframes = min(t0 + gm.TT, gm.maxT) - t0;
   const int rows_blk = nframes * maxU1;  // frames at or beyond T_b are included: they are zero-filled
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(kRowBlock) void k_grad(const float* x, float* grad,
       coef_s[i] = cf;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) w.hdr->n_partial = gm.nblocks;
+  if (blockIdx.x == 0 && threadIdx.x == 0) w.hdr->n_partial = gm.nblocks_all;
   __syncthreads();
 
   RowCursor<G> cur;
@@ -694,7 +699,7 @@ __global__ __launch_bounds__(kRowBlock) void k_grad(const float* x, float* grad,
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < kRowWaves; ++i) s += red[i];
-    w.partial[bid] = s;
+    w.partial[gm.b0 * gm.nTB + bid] = s;
   }
 }
 
@@ -766,7 +771,9 @@ RowCfg pick_row_cfg(int B, int maxT, int maxU1, int V, int blank, const void* p0
   c.gm.TT = TT;
   c.gm.nTB = (maxT + TT - 1) / TT;
   c.gm.npass = (cpl + c.nc - 1) / c.nc;
+  c.gm.b0 = 0;
   c.gm.nblocks = B * c.gm.nTB;
+  c.gm.nblocks_all = B * c.gm.nTB;
   return c;
 }
 
@@ -798,32 +805,84 @@ int check_shape(int B, int maxT, int maxU1, int V, int blank) {
 
 int launch_status() { return hipGetLastError() == hipSuccess ? RNNT_MI355X_OK : RNNT_MI355X_LAUNCH_FAILURE; }
 
-int launch_forward(const float* logits, const int32_t* labels, const int32_t* in_len, const int32_t* lab_len, int B,
-                   int maxT, int maxU1, int V, int blank, float* costs, void* workspace, hipStream_t st) {
+struct Call {
+  const float* logits;
+  float* grad;
+  const int32_t* labels;
+  const int32_t* in_len;
+  const int32_t* lab_len;
+  int B, maxT, maxU1, V, blank;
+  const float* grad_scale;
+  float* costs;
   Ws w;
-  ws_layout(workspace, B, maxT, maxU1, &w);
-  const RowCfg cfg = pick_row_cfg(B, maxT, maxU1, V, blank, logits, logits);
-  k_init<<<1, 64, 0, st>>>(w, 0);
-  RNNT_DISPATCH(k_lse, cfg, sizeof(float4) * (size_t)cfg.gm.TT * maxU1, logits, labels, in_len, lab_len, cfg.gm, w);
-  const int grid = 2 * B;
-  switch (sweep_cols_per_lane(maxU1)) {
-    case 1: k_sweep<1><<<grid, 64, 0, st>>>(w, costs, in_len, lab_len, B, maxT, maxU1); break;
-    case 2: k_sweep<2><<<grid, 64, 0, st>>>(w, costs, in_len, lab_len, B, maxT, maxU1); break;
-    case 4: k_sweep<4><<<grid, 64, 0, st>>>(w, costs, in_len, lab_len, B, maxT, maxU1); break;
-    default: k_sweep<8><<<grid, 64, 0, st>>>(w, costs, in_len, lab_len, B, maxT, maxU1); break;
+};
+
+RowCfg sub_cfg(const Call& c, const void* p1, int b0, int nb) {
+  RowCfg cfg = pick_row_cfg(c.B, c.maxT, c.maxU1, c.V, c.blank, c.logits, p1);
+  cfg.gm.b0 = b0;
+  cfg.gm.nblocks = nb * cfg.gm.nTB;
+  return cfg;
+}
+
+void launch_lse(const Call& c, int b0, int nb, hipStream_t st) {
+  const RowCfg cfg = sub_cfg(c, c.logits, b0, nb);
+  RNNT_DISPATCH(k_lse, cfg, sizeof(float4) * (size_t)cfg.gm.TT * c.maxU1, c.logits, c.labels, c.in_len, c.lab_len,
+                cfg.gm, c.w);
+}
+
+void launch_sweep(const Call& c, int b0, int nb, hipStream_t st) {
+  const int grid = 2 * nb;
+  switch (sweep_cols_per_lane(c.maxU1)) {
+    case 1: k_sweep<1><<<grid, 64, 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0); break;
+    case 2: k_sweep<2><<<grid, 64, 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0); break;
+    case 4: k_sweep<4><<<grid, 64, 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0); break;
+    default: k_sweep<8><<<grid, 64, 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0); break;
   }
+}
+
+void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
+  const RowCfg cfg = sub_cfg(c, c.grad, b0, nb);
+  RNNT_DISPATCH(k_grad, cfg, sizeof(float4) * (size_t)cfg.gm.TT * c.maxU1, c.logits, c.grad, c.labels, c.in_len,
+                c.lab_len, c.grad_scale, cfg.gm, c.w);
+}
+
+int launch_forward(const Call& c, hipStream_t st) {
+  k_init<<<1, 64, 0, st>>>(c.w, 0);
+  launch_lse(c, 0, c.B, st);
+  launch_sweep(c, 0, c.B, st);
   return launch_status();
 }
 
-int launch_backward(const float* logits, float* grad, const int32_t* labels, const int32_t* in_len,
-                    const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank, const float* grad_scale,
-                    void* workspace, hipStream_t st) {
-  Ws w;
-  ws_layout(workspace, B, maxT, maxU1, &w);
-  const RowCfg cfg = pick_row_cfg(B, maxT, maxU1, V, blank, logits, grad);
-  RNNT_DISPATCH(k_grad, cfg, sizeof(float4) * (size_t)cfg.gm.TT * maxU1, logits, grad, labels, in_len, lab_len,
-                grad_scale, cfg.gm, w);
+int launch_backward(const Call& c, hipStream_t st) {
+  launch_grad(c, 0, c.B, st);
   return launch_status();
+}
+
+// forward + backward on the caller's stream.  ev_begin / ev_end (optional hipEvent_t) bracket the gradient
+// launch.  (Running the latency-bound sweep of one half of the batch on a second stream underneath the
+// streaming kernels of the other half was measured and rejected: the sweep is hidden, but two extra kernel
+// tails and its interference cost as much as the 0.1 ms it saves.)
+int launch_loss_grad(const Call& c, hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end) {
+  int rc = launch_forward(c, st);
+  if (rc != RNNT_MI355X_OK) return rc;
+  if (ev_begin && hipEventRecord(ev_begin, st) != hipSuccess) return RNNT_MI355X_LAUNCH_FAILURE;
+  rc = launch_backward(c, st);
+  if (ev_end && hipEventRecord(ev_end, st) != hipSuccess) return RNNT_MI355X_LAUNCH_FAILURE;
+  return rc;
+}
+
+int make_call(Call* c, const float* logits, float* grad, const int32_t* labels, const int32_t* in_len,
+              const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank, const float* grad_scale,
+              float* costs, void* workspace, bool need_grad, bool need_costs) {
+  const int rc = check_shape(B, maxT, maxU1, V, blank);
+  if (rc != RNNT_MI355X_OK) return rc;
+  if (!logits || !in_len || !lab_len || !workspace || (maxU1 > 1 && !labels)) return RNNT_MI355X_INVALID_VALUE;
+  if ((need_grad && !grad) || (need_costs && !costs)) return RNNT_MI355X_INVALID_VALUE;
+  c->logits = logits; c->grad = grad; c->labels = labels; c->in_len = in_len; c->lab_len = lab_len;
+  c->B = B; c->maxT = maxT; c->maxU1 = maxU1; c->V = V; c->blank = blank;
+  c->grad_scale = grad_scale; c->costs = costs;
+  ws_layout(workspace, B, maxT, maxU1, &c->w);
+  return RNNT_MI355X_OK;
 }
 
 }  // namespace
@@ -854,23 +913,21 @@ int rnnt_mi355x_workspace_bytes(int B, int maxT, int maxU1, size_t* out_bytes) {
 int rnnt_mi355x_forward(const float* logits, const int32_t* labels, const int32_t* in_len, const int32_t* lab_len,
                         int B, int maxT, int maxU1, int V, int blank, float* costs, void* workspace,
                         void* hip_stream) {
-  const int rc = check_shape(B, maxT, maxU1, V, blank);
+  Call c;
+  const int rc = make_call(&c, logits, nullptr, labels, in_len, lab_len, B, maxT, maxU1, V, blank, nullptr, costs,
+                           workspace, false, true);
   if (rc != RNNT_MI355X_OK) return rc;
-  if (!logits || !in_len || !lab_len || !costs || !workspace || (maxU1 > 1 && !labels))
-    return RNNT_MI355X_INVALID_VALUE;
-  return launch_forward(logits, labels, in_len, lab_len, B, maxT, maxU1, V, blank, costs, workspace,
-                        static_cast<hipStream_t>(hip_stream));
+  return launch_forward(c, static_cast<hipStream_t>(hip_stream));
 }
 
 int rnnt_mi355x_backward(const float* logits, float* grad, const int32_t* labels, const int32_t* in_len,
                          const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank, const float* grad_scale,
                          void* workspace, void* hip_stream) {
-  const int rc = check_shape(B, maxT, maxU1, V, blank);
+  Call c;
+  const int rc = make_call(&c, logits, grad, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale, nullptr,
+                           workspace, true, false);
   if (rc != RNNT_MI355X_OK) return rc;
-  if (!logits || !grad || !in_len || !lab_len || !workspace || (maxU1 > 1 && !labels))
-    return RNNT_MI355X_INVALID_VALUE;
-  return launch_backward(logits, grad, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale, workspace,
-                         static_cast<hipStream_t>(hip_stream));
+  return launch_backward(c, static_cast<hipStream_t>(hip_stream));
 }
 
 int rnnt_mi355x_backward_inplace(float* logits_inout, const int32_t* labels, const int32_t* in_len,
@@ -883,11 +940,20 @@ int rnnt_mi355x_backward_inplace(float* logits_inout, const int32_t* labels, con
 int rnnt_mi355x_loss_grad(float* logits_inout, const int32_t* labels, const int32_t* in_len, const int32_t* lab_len,
                           int B, int maxT, int maxU1, int V, int blank, const float* grad_scale, float* costs,
                           void* workspace, void* hip_stream) {
-  const int rc = rnnt_mi355x_forward(logits_inout, labels, in_len, lab_len, B, maxT, maxU1, V, blank, costs,
-                                     workspace, hip_stream);
+  return rnnt_mi355x_loss_grad_events(logits_inout, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale,
+                                      costs, workspace, hip_stream, nullptr, nullptr);
+}
+
+int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, const int32_t* in_len,
+                                 const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
+                                 const float* grad_scale, float* costs, void* workspace, void* hip_stream,
+                                 void* ev_grad_begin, void* ev_grad_end) {
+  Call c;
+  const int rc = make_call(&c, logits_inout, logits_inout, labels, in_len, lab_len, B, maxT, maxU1, V, blank,
+                           grad_scale, costs, workspace, true, true);
   if (rc != RNNT_MI355X_OK) return rc;
-  return rnnt_mi355x_backward(logits_inout, logits_inout, labels, in_len, lab_len, B, maxT, maxU1, V, blank,
-                              grad_scale, workspace, hip_stream);
+  return launch_loss_grad(c, static_cast<hipStream_t>(hip_stream), static_cast<hipEvent_t>(ev_grad_begin),
+                          static_cast<hipEvent_t>(ev_grad_end));
 }
 
 int rnnt_mi355x_reduce_scalars(const float* costs, int B, void* workspace, double* out2, void* hip_stream) {

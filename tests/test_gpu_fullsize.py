@@ -1,0 +1,144 @@
+"""BASELINE-sized runs on the GPU, checked through size-independent
+properties (the float64 oracle cannot afford the whole tensor) plus exact
+oracle parity on a sampled subset of utterances.
+
+Properties used:
+  * every gradient row sums to zero (softmax backward of a function of the
+    log-probabilities);
+  * identical utterances give bit-identical costs and gradients wherever they
+    sit in the batch (also beyond the 2^31-element mark of the logits tensor);
+  * cells beyond an utterance's lengths are exact zeros;
+  * rows the gradient kernel prunes are rows whose exact gradient is negligible.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rnnt_oracle as orc
+from tests.hip_runner import HipRun
+
+pytestmark = pytest.mark.gpu
+COST_RTOL = 1e-5
+GRAD_ATOL = 1e-4
+
+
+def _gpu_batch(B, T, U, V, blank, seed, il=None, ll=None):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = torch.empty((B, T, U + 1, V), dtype=torch.float32, device=dev).normal_(generator=g)
+    lab = torch.randint(0, V - 1, (B, U), generator=g, device=dev, dtype=torch.int32)
+    lab = lab + (lab >= blank).to(torch.int32)
+    il = np.full(B, T, np.int32) if il is None else il
+    ll = np.full(B, U, np.int32) if ll is None else ll
+    return x, lab, il, ll
+
+
+def _run(x, lab, il, ll, blank, gs=None):
+    run = HipRun.__new__(HipRun)
+    import ctypes
+    from rnnt_amd import _lib
+    run.dev = x.device
+    run.B, run.T, run.U1, run.V = x.shape
+    run.blank = blank
+    run.x, run.lab = x, lab
+    run.il = torch.from_numpy(il).to(x.device)
+    run.ll = torch.from_numpy(ll).to(x.device)
+    run.gs = gs
+    run.ws = torch.empty(_lib.workspace_bytes(run.B, run.T, run.U1), dtype=torch.uint8, device=x.device)
+    run.costs = torch.full((run.B,), float("nan"), dtype=torch.float32, device=x.device)
+    run.stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    assert run.loss_grad() == 0
+    torch.cuda.synchronize()
+    assert run.flags() == (0, 0)
+    return run
+
+
+def _subset_parity(x_before, run, lab, il, ll, blank, picks, scale=1.0):
+    for b in picks:
+        T, U = int(il[b]), int(ll[b])
+        xb = x_before[b:b + 1, :T, :U + 1].cpu().numpy()
+        co, go = orc.rnnt_loss_and_grad(xb, lab[b:b + 1, :U].cpu().numpy(), [T], [U], blank, [scale])
+        np.testing.assert_allclose(run.costs[b].item(), co[0], rtol=COST_RTOL)
+        got = run.x[b, :T, :U + 1].cpu().numpy()
+        assert np.abs(got - go).max() < GRAD_ATOL
+
+
+def test_config3_full_size_properties_and_subset_parity():
+    """B=64 T=400 U=100 V=1024 (10.6 GB of logits; 2.65e9 elements > 2^31)."""
+    B, T, U, V, blank = 64, 400, 100, 1024, 1023
+    x, lab, il, ll = _gpu_batch(B, T, U, V, blank, seed=0xC0FFEE + 3)
+    # utterances 5 and 61 are copies of utterance 0 (one before, one beyond the 2^31-element mark)
+    x[5].copy_(x[0]); x[61].copy_(x[0]); lab[5].copy_(lab[0]); lab[61].copy_(lab[0])
+    keep = {b: x[b].clone() for b in (0, 63)}
+    run = _run(x, lab, il, ll, blank)
+    assert torch.isfinite(run.costs).all()
+    assert torch.equal(run.costs[5], run.costs[0]) and torch.equal(run.costs[61], run.costs[0])
+    assert torch.equal(run.x[5], run.x[0]) and torch.equal(run.x[61], run.x[0])
+    rows = run.x.sum(-1)
+    assert rows.abs().max().item() < 2e-5          # every gradient row sums to ~0
+    assert torch.isfinite(run.x[63]).all()
+    before = torch.stack([keep[0], keep[63]])
+    sub = HipRun.__new__(HipRun)
+    sub.costs = run.costs[[0, 63]]
+    sub.x = run.x[[0, 63]]
+    _subset_parity(before, sub, lab[[0, 63]], il[[0, 63]], ll[[0, 63]], blank, [0, 1])
+
+
+def test_config2_full_size_subset_parity():
+    """B=32 T=500 U=100 V=62, blank=39 (reference util.py:72)."""
+    B, T, U, V, blank = 32, 500, 100, 62, 39
+    x, lab, il, ll = _gpu_batch(B, T, U, V, blank, seed=0xC0FFEE + 2)
+    before = x[[0, 17, 31]].clone()
+    run = _run(x, lab, il, ll, blank)
+    assert run.x.sum(-1).abs().max().item() < 2e-5
+    sub = HipRun.__new__(HipRun)
+    sub.costs, sub.x = run.costs[[0, 17, 31]], run.x[[0, 17, 31]]
+    _subset_parity(before, sub, lab[[0, 17, 31]], il[[0, 17, 31]], ll[[0, 17, 31]], blank, [0, 1, 2])
+
+
+def test_config4_vocab_reduced_batch():
+    """V=4096, T=250, U=150 with B=4 (the per-GPU share of config 4 on 8 GPUs)."""
+    B, T, U, V, blank = 4, 250, 150, 4096, 4095
+    x, lab, il, ll = _gpu_batch(B, T, U, V, blank, seed=0xC0FFEE + 4)
+    before = x[[1]].clone()
+    gs = torch.full((B,), 1.0 / 32, device=x.device)
+    run = _run(x, lab, il, ll, blank, gs)
+    assert run.x.sum(-1).abs().max().item() < 1e-6
+    sub = HipRun.__new__(HipRun)
+    sub.costs, sub.x = run.costs[[1]], run.x[[1]]
+    _subset_parity(before, sub, lab[[1]], il[[1]], ll[[1]], blank, [0], scale=1.0 / 32)
+
+
+def test_config5_ragged_padded_cells_and_subset_parity():
+    """Ragged lengths T in [50,1000], U in [10,200], V=512, B=16 of the 128."""
+    B, T, U, V, blank = 16, 1000, 200, 512, 511
+    rng = np.random.default_rng(0xC0FFEE + 7)
+    il = rng.integers(50, T + 1, B).astype(np.int32)
+    ll = rng.integers(10, U + 1, B).astype(np.int32)
+    il[3], ll[3] = T, U      # one utterance at both maxima
+    il[4], ll[4] = 50, 10    # one at both minima
+    x, lab, _, _ = _gpu_batch(B, T, U, V, blank, seed=11)
+    picks = [3, 4, 9]
+    before = x[picks].clone()
+    run = _run(x, lab, il, ll, blank)
+    for b in range(B):
+        assert not run.x[b, il[b]:].any() and not run.x[b, :, ll[b] + 1:].any()
+    sub = HipRun.__new__(HipRun)
+    sub.costs, sub.x = run.costs[picks], run.x[picks]
+    _subset_parity(before, sub, lab[picks], il[picks], ll[picks], blank, [0, 1, 2])
+
+
+def test_pruned_rows_are_truly_negligible():
+    """Rows the gradient kernel zero-fills without reading (occupancy below
+    2^-40) must be ones whose exact gradient is below 1e-11 everywhere."""
+    B, T, U, V, blank = 1, 300, 80, 64, 63
+    x, lab, il, ll = _gpu_batch(B, T, U, V, blank, seed=5)
+    xh = x.cpu().numpy()
+    run = _run(x, lab, il, ll, blank)
+    _, go = orc.rnnt_loss_and_grad(xh, lab.cpu().numpy(), il, ll, blank)
+    g = run.x.cpu().numpy()
+    zero_rows = ~g.any(-1)
+    assert zero_rows.mean() > 0.2                       # the prune does fire at this size
+    assert np.abs(go[zero_rows]).max() < 1e-11
+    assert np.abs(g - go).max() < 2e-5

@@ -37,6 +37,7 @@ for path in a.libs:
 meta = (B, T, U1, V, blank)
 res = {n: ([], []) for n, _, _ in libs}
 ref = None
+fused = {}
 for r in range(a.rounds + 1):
     for name, L, ws in libs:
         buf.copy_(master)
@@ -48,6 +49,13 @@ for r in range(a.rounds + 1):
         e[2].record()
         torch.cuda.synchronize()
         assert rc == 0
+        if hasattr(L, "rnnt_mi355x_loss_grad_events") and r > 0:
+            buf.copy_(master)
+            f0 = torch.cuda.Event(enable_timing=True); f1 = torch.cuda.Event(enable_timing=True)
+            f0.record()
+            rc = L.rnnt_mi355x_loss_grad(p(buf), p(labels), p(il), p(ll), *meta, p(gs), p(costs), p(ws), sp)
+            f1.record(); torch.cuda.synchronize(); assert rc == 0
+            fused.setdefault(name, []).append(f0.elapsed_time(f1))
         if r == 0:
             c = costs.clone(); g = buf[0, :2].clone()
             if ref is None: ref = (c, g)
@@ -57,4 +65,5 @@ for r in range(a.rounds + 1):
 cells = int((il_h.astype(np.int64) * (ll_h + 1)).sum())
 for name, (f, bk) in res.items():
     tot = np.median(f) + np.median(bk)
+    if name in fused: print(f"{name:22s} fused loss_grad med {np.median(fused[name]):7.3f} min {min(fused[name]):7.3f} ms  frac {cells*(8*V+16)/np.median(fused[name])/1e-3/8e12:.3f}")
     print(f"{name:22s} fwd med {np.median(f):7.3f} min {min(f):7.3f} | bwd med {np.median(bk):7.3f} min {min(bk):7.3f} | sum {tot:7.3f} ms  {cells/tot/1e6:8.1f} Mcells/s  frac {cells*(8*V+16)/tot/1e-3/8e12:.3f}")
