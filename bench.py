@@ -103,6 +103,12 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
+
+    def dbg(msg):
+        if os.environ.get("BENCH_DEBUG"):
+            print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,8 +123,11 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "gloo":  # single-node rehearsal: the host name may not resolve
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group(args.backend, rank=rank, world_size=world, **({"device_id": dev} if args.backend == "nccl" else {}))
 
+    dbg("process group ready")
     from rnnt_amd import _lib
     L = _lib.lib()
 
@@ -178,14 +187,22 @@ def main():
         if rc != 0:
             raise RuntimeError(f"rnnt_mi355x call failed: status {rc}")
         if world > 1:
-            dist.all_reduce(scal)
+            if args.backend == "nccl":
+                dist.all_reduce(scal)  # RCCL, enqueued behind the step on the device
+            else:  # gloo rehearsal: reduce a host copy
+                host = scal.cpu()
+                dist.all_reduce(host)
+
+    # barrier = a 1-element all-reduce (on the device for RCCL, on the host for gloo rehearsals)
+    bar = torch.zeros(1, dtype=torch.float32, device=dev if args.backend == "nccl" else "cpu")
 
     def fence():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
+            dist.all_reduce(bar)
             torch.cuda.synchronize(dev)
 
+    dbg(f"buffers ready (ring {ring_n})")
     # warmup
     done = 0
     while done < args.warmup:
@@ -194,6 +211,7 @@ def main():
         for i in range(n):
             step(ring[i], False)
         done += n
+    dbg("warmup done")
     # timed: segments of at most ring_n steps, refill between segments untimed
     elapsed = 0.0
     done = 0
@@ -207,6 +225,7 @@ def main():
         fence()
         elapsed += time.perf_counter() - t0
         done += n
+    dbg("timed region done")
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
