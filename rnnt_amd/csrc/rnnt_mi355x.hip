@@ -54,7 +54,10 @@ struct Ws {
   Header* hdr;
   double* ll;      // [2][B]  log2-likelihood from alpha / from beta
   float* partial;  // [B*maxT] per-block sum of squared gradient elements
-  float4* rec;     // [B][maxT][maxU1] {log2 P(blank|t,u), log2 P(label u+1|t,u), log2-sum-exp2 of the row, 0}
+  // [B][maxT+2][maxU1] {log2 P(blank|t,u), log2 P(label u+1|t,u), log2-sum-exp2 of the row, 0}; frame t lives at
+  // index t+1, frames -1 and maxT are guards.  Every entry that is not a lattice cell (guards, t >= T_b,
+  // u > U_b) and the label slot of column U_b hold "log 0", so the sweeps need no masks.
+  float4* rec;
   double* alpha;   // [B][D][U1s]
   double* beta;    // [B][D][U1s]
   size_t partial_off;
@@ -84,7 +87,7 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w) {
   const size_t o_hdr = take(sizeof(Header));
   const size_t o_ll = take(sizeof(double) * 2 * B);
   const size_t o_partial = take(sizeof(float) * (size_t)B * maxT);
-  const size_t o_rec = take(sizeof(float4) * (size_t)B * maxT * maxU1);
+  const size_t o_rec = take(sizeof(float4) * (size_t)B * (maxT + 2) * maxU1);
   const size_t o_alpha = take(sizeof(double) * plane);
   const size_t o_beta = take(sizeof(double) * plane);
   if (w) {
@@ -170,6 +173,7 @@ __device__ __forceinline__ float dpp_mov(float v) {
 template <int L, typename Op>
 __device__ __forceinline__ float group_reduce(float v, Op op) {
   static_assert(L == 8 || L == 16 || L == 32 || L == 64, "group size");
+
   v = op(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
   v = op(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
   v = op(v, dpp_mov<0x141>(v));  // row_half_mirror
@@ -235,6 +239,7 @@ struct LseTile {
   float v[G][NC][VEC];
   float xb[G], xl[G];  // lane j==0, pass 0: logits of blank and of the next label
   int rho[G];          // row inside the block, -1 = the row holds no cell
+  int haslab[G];
   int pass;
 };
 
@@ -251,14 +256,18 @@ __global__ __launch_bounds__(kRowBlock) void k_lse(const float* __restrict__ x, 
   const int t0 = (blockIdx.x - bl * gm.nTB) * gm.TT;
   int T, U;
   utt_dims(in_len, lab_len, b, gm.maxT, gm.maxU1, T, U);
-  if (t0 >= T) return;  // frames at or beyond T_b hold no lattice cell
-  const int rows_blk = (min(t0 + gm.TT, T) - t0) * gm.maxU1;
-  const int ntiles = ((rows_blk + S - 1) / S) * gm.npass;
+  // frames at or beyond T_b hold no lattice cell: their logits are not read, their records are "log 0"
+  const int rows_cell = (max(min(t0 + gm.TT, T), t0) - t0) * gm.maxU1;
+  const int rows_blk = (min(t0 + gm.TT, gm.maxT) - t0) * gm.maxU1;
+  const int ntiles = ((rows_cell + S - 1) / S) * gm.npass;
   const int V = gm.V, blank = gm.blank, maxU1 = gm.maxU1, npass = gm.npass;
   const int nchunk = V / VEC;
   const int sq = S / maxU1, sr = S % maxU1;
   const float* xblk = x + (size_t)(b * gm.maxT + t0) * maxU1 * V;
   extern __shared__ float4 recs[];  // this block's records, written out in one coalesced burst at the end
+
+  for (int i = threadIdx.x; i < rows_blk; i += kRowBlock) recs[i] = make_float4(kNegF, kNegF, 0.f, 0.f);
+  __syncthreads();
 
   RowCursor<G> cur;
   cur.init(wv * G * R + r, R, maxU1);
@@ -271,8 +280,9 @@ __global__ __launch_bounds__(kRowBlock) void k_lse(const float* __restrict__ x, 
     tl.pass = cur.pass;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const bool valid = (cur.rho[g] < rows_blk) & (cur.uu[g] <= U);
+      const bool valid = (cur.rho[g] < rows_cell) & (cur.uu[g] <= U);
       tl.rho[g] = valid ? cur.rho[g] : -1;
+      tl.haslab[g] = valid & (cur.uu[g] < U);
       const float* rp = xblk + (size_t)(valid ? cur.rho[g] : 0) * V;
       tl.xb[g] = 0.f;
       tl.xl[g] = 0.f;
@@ -333,8 +343,8 @@ __global__ __launch_bounds__(kRowBlock) void k_lse(const float* __restrict__ x, 
         const float s_all = group_sum<L>(s_run[g]);
         const float lse2 = m_run[g] * kLog2e + fast_log2(s_all);
         if (tl.rho[g] >= 0 && j == 0)
-          recs[tl.rho[g]] = make_float4(__builtin_fmaf(exb[g], kLog2e, -lse2), __builtin_fmaf(exl[g], kLog2e, -lse2),
-                                        lse2, 0.f);
+          recs[tl.rho[g]] = make_float4(__builtin_fmaf(exb[g], kLog2e, -lse2),
+                                        tl.haslab[g] ? __builtin_fmaf(exl[g], kLog2e, -lse2) : kNegF, lse2, 0.f);
       }
     }
   };
@@ -348,10 +358,16 @@ __global__ __launch_bounds__(kRowBlock) void k_lse(const float* __restrict__ x, 
     if (s + 2 < ntiles) issue(ta);
     consume(tb);
   }
-  // rows beyond U_b carry stale LDS bytes; every reader masks them out
   __syncthreads();
-  float4* out = w.rec + (size_t)(b * gm.maxT + t0) * maxU1;
+  float4* frame0 = w.rec + ((size_t)b * (gm.maxT + 2) + 1) * maxU1;  // frame 0 of this utterance
+  float4* out = frame0 + (size_t)t0 * maxU1;
   for (int i = threadIdx.x; i < rows_blk; i += kRowBlock) out[i] = recs[i];
+  // the first and the last block of an utterance also write its guard frames
+  const float4 neg = make_float4(kNegF, kNegF, 0.f, 0.f);
+  if (t0 == 0)
+    for (int i = threadIdx.x; i < maxU1; i += kRowBlock) (frame0 - maxU1)[i] = neg;
+  if (t0 + gm.TT >= gm.maxT)
+    for (int i = threadIdx.x; i < maxU1; i += kRowBlock) (frame0 + (size_t)gm.maxT * maxU1)[i] = neg;
 }
 
 // ---------------------------------------------------------------------------
@@ -364,13 +380,6 @@ __global__ __launch_bounds__(kRowBlock) void k_lse(const float* __restrict__ x, 
 // themselves.  The log-prob rows of the next P diagonals are kept in flight in
 // a register ring.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double log2_add(double p, double q) {
-  const double mx = fmax(p, q);
-  const double mn = fmin(p, q);
-  const float df = (float)(mn - mx);  // <= 0
-  return mx + (double)fast_log2(1.0f + fast_exp2(df));
-}
-
 // lane i receives lane i-1's value; lane 0 receives `fill`
 __device__ __forceinline__ double lane_shift_up(double v, double fill) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -386,33 +395,38 @@ __device__ __forceinline__ double lane_shift_down(double v, double fill) {
   return __hiloint2double(hi, lo);
 }
 
-// Log-probs {blank, label} of the lattice cells (d-u, u) for this lane's K columns, "log 0" where the cell
-// (or its label move) does not exist.  Records are in [t][u] order, so the lanes of a diagonal read with a
-// stride of maxU1-1 records; the rows stay in L1 for the 8 diagonals that share a cache line.
+// Log-probs {blank, label} of the cells (d-u, u) of diagonal d for this lane's K columns.  Records are in [t][u]
+// order, so the lanes of a diagonal read with a stride of maxU1-1 records; a cache line serves 8 diagonals.
+// Frames are clamped into the guard frames (-1 and maxT), columns beyond maxU1-1 read column maxU1-1 of the
+// guard frame; everything outside the lattice reads "log 0".  rec0 = record of frame -1, column 0.
 template <int K>
-__device__ __forceinline__ void load_lp_diag(const float4* rec, int d, int maxU1, int u0, const int (&lo)[K],
-                                             const int (&hi)[K], const int (&hil)[K], float (&pb)[K], float (&pl)[K]) {
+__device__ __forceinline__ void load_lp_diag(const float4* rec0, int d, int maxT, int maxU1, const int (&ucol)[K],
+                                             const int (&uoff)[K], float (&pb)[K], float (&pl)[K]) {
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const int u = u0 + i;
-    const bool in_b = (d >= lo[i]) & (d <= hi[i]);
-    const bool in_l = (d >= lo[i]) & (d <= hil[i]);
-    const int idx = in_b ? (d - u) * maxU1 + u : 0;
-    const float2 q = *reinterpret_cast<const float2*>(rec + idx);
-    pb[i] = in_b ? q.x : kNegF;
-    pl[i] = in_l ? q.y : kNegF;
+    const int t1 = min(max(d - ucol[i], -1), maxT) + 1;                    // frame index incl. guards (v_med3_i32)
+    const unsigned off = (unsigned)(t1 * maxU1 + uoff[i]);                 // uoff = min(u, maxU1-1), or a guard slot
+    const float2 q = *reinterpret_cast<const float2*>(rec0 + off);
+    pb[i] = q.x;
+    pl[i] = q.y;
   }
 }
 
 template <int K>
-__device__ __forceinline__ void store_row(double* base, int row, int U1s, int u0, const double (&v)[K]) {
-  double* p = base + (size_t)row * U1s + u0;
+__device__ __forceinline__ void store_row(double* base, int row, unsigned U1s, int u0, const double (&v)[K]) {
+  double* p = base + ((unsigned)row * U1s + (unsigned)u0);
   if constexpr (K == 1) {
     p[0] = v[0];
   } else {
 #pragma unroll
     for (int i = 0; i < K; i += 2) *reinterpret_cast<double2*>(p + i) = make_double2(v[i], v[i + 1]);
   }
+}
+
+// log2(2^x + 2^y) with the sum in float64 and the correction term in float32
+__device__ __forceinline__ double log2_add(double x, double y) {
+  const float df = (float)(x - y);
+  return fmax(x, y) + (double)fast_log2(1.0f + fast_exp2(-fabsf(df)));
 }
 
 template <int K>
@@ -434,20 +448,20 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
     return;
   }
   const int T = Traw, U = Uraw;
-  const int U1s = w.U1s;
+  const unsigned U1s = (unsigned)w.U1s;
   const size_t plane = (size_t)b * w.D * U1s;
-  const float4* rec = w.rec + (size_t)b * maxT * maxU1;
+  const float4* rec0 = w.rec + (size_t)b * (maxT + 2) * maxU1;  // frame -1 (guard), column 0
   const int u0 = lane * K;
   const int dlast = T - 1 + U;
 
-  // cell (d-u, u) is in the lattice iff lo <= d <= hi; it has a label move iff also d <= hil
-  int lo[K], hi[K], hil[K];
+  // columns beyond maxU1-1 have no record: they read the guard frame (frame index forced to -1 by a huge column)
+  int ucol[K], uoff[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const int u = u0 + i;
-    lo[i] = u;
-    hi[i] = (u <= U) ? u + T - 1 : -1;
-    hil[i] = (u < U) ? u + T - 1 : -1;
+    const bool has = u < maxU1;
+    ucol[i] = has ? u : (1 << 28);
+    uoff[i] = has ? u : 0;
   }
 
   if (dir == 0) {
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
 #pragma unroll
     for (int i = 0; i < K; ++i) a[i] = (u0 + i == 0) ? 0.0 : kNeg;
     store_row<K>(alpha, 0, U1s, u0, a);
-    // one diagonal: a <- alpha(d) from alpha(d-1) and the (masked) log-probs of diagonal d-1
+    // one diagonal: a <- alpha(d) from alpha(d-1) and the log-probs of diagonal d-1
     auto step = [&](int d, const float (&pb)[K], const float (&pl)[K]) {
       double el[K];
 #pragma unroll
@@ -470,19 +484,18 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
     // remainder first, so that the pipelined loop below runs whole groups of P
     for (const int rem = dlast % P; d <= rem; ++d) {
       float pb[K], pl[K];
-      load_lp_diag<K>(rec, d - 1, maxU1, u0, lo, hi, hil, pb, pl);
+      load_lp_diag<K>(rec0, d - 1, maxT, maxU1, ucol, uoff, pb, pl);
       step(d, pb, pl);
     }
     if (d <= dlast) {
       float pb[P][K], pl[P][K];
 #pragma unroll
-      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec, d - 1 + p, maxU1, u0, lo, hi, hil, pb[p], pl[p]);
+      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec0, d - 1 + p, maxT, maxU1, ucol, uoff, pb[p], pl[p]);
       for (; d <= dlast; d += P) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           step(d + p, pb[p], pl[p]);
-          // past the last diagonal every cell is masked, so the refill needs no clamp
-          load_lp_diag<K>(rec, d + p - 1 + P, maxU1, u0, lo, hi, hil, pb[p], pl[p]);
+          load_lp_diag<K>(rec0, d + p - 1 + P, maxT, maxU1, ucol, uoff, pb[p], pl[p]);
           __builtin_amdgcn_sched_barrier(0);  // keep the refill P diagonals ahead of its use
         }
       }
@@ -491,7 +504,7 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       if (u0 + i == U) {
-        const double ll2 = a[i] + (double)rec[(size_t)(T - 1) * maxU1 + U].x;
+        const double ll2 = a[i] + (double)rec0[(size_t)T * maxU1 + U].x;  // frame T-1 is at index T
         w.ll[b] = ll2;
         costs[b] = (float)(-ll2 * kLn2);
       }
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
     double bt[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) bt[i] = (u0 + i == U) ? 0.0 : kNeg;
-    // one diagonal: bt <- beta(d) from beta(d+1) and the (masked) log-probs of diagonal d
+    // one diagonal: bt <- beta(d) from beta(d+1) and the log-probs of diagonal d
     auto step = [&](int d, const float (&pb)[K], const float (&pl)[K]) {
       const double from_right = lane_shift_down(bt[0], kNeg);
       double nb[K];
@@ -516,19 +529,18 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
     int d = dlast;
     for (int rem = (dlast + 1) % P; rem > 0; --rem, --d) {
       float pb[K], pl[K];
-      load_lp_diag<K>(rec, d, maxU1, u0, lo, hi, hil, pb, pl);
+      load_lp_diag<K>(rec0, d, maxT, maxU1, ucol, uoff, pb, pl);
       step(d, pb, pl);
     }
     if (d >= 0) {
       float pb[P][K], pl[P][K];
 #pragma unroll
-      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec, d - p, maxU1, u0, lo, hi, hil, pb[p], pl[p]);
+      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec0, d - p, maxT, maxU1, ucol, uoff, pb[p], pl[p]);
       for (; d >= 0; d -= P) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           step(d - p, pb[p], pl[p]);
-          // below diagonal 0 every cell is masked (d < lo), so the refill needs no clamp
-          load_lp_diag<K>(rec, d - p - P, maxU1, u0, lo, hi, hil, pb[p], pl[p]);
+          load_lp_diag<K>(rec0, d - p - P, maxT, maxU1, ucol, uoff, pb[p], pl[p]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -596,7 +608,7 @@ __global__ __launch_bounds__(kRowBlock) void k_grad(const float* x, float* grad,
       if (t < T && u <= U) {
         const size_t ci = plane + (size_t)(t + u) * U1s + u;
         const double a_ll = w.alpha[ci] - ll2;
-        const float4 rc = w.rec[blk_row0 + i];          // {lpb, lpl, lse, -}
+        const float4 rc = w.rec[((size_t)b * (gm.maxT + 2) + 1 + t) * maxU1 + u];  // {lpb, lpl, lse, -}
         const float g2 = (float)(a_ll + w.beta[ci]);   // log2 gamma
         if (g2 >= kPruneLog2) {
           float e_b = -INFINITY;  // 2^-inf = 0: no blank move out of this cell
