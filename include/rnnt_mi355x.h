@@ -85,6 +85,21 @@ int rnnt_mi355x_backward_inplace(float* logits_inout, const int32_t* labels, con
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
                                  const float* grad_scale, void* workspace, void* hip_stream);
 
+/* rnnt_mi355x_forward / rnnt_mi355x_backward on tensors whose utterances are
+ * `*_batch_stride` ELEMENTS apart (>= maxT*maxU1*V; inside an utterance the
+ * layout stays [maxT, maxU1, V] contiguous).  This is how the crop of the
+ * first two frames, `acts[:, 2:, :, :]` at reference util.py:63 (and
+ * `y_trans[:, 2:, :]` at util.py:101), is taken without copying the tensor:
+ * pass the address of frame 2 of utterance 0, the uncropped batch stride and
+ * maxT = T0 - 2.  `grad` may alias `logits` when both strides are equal. */
+int rnnt_mi355x_forward_strided(const float* logits, size_t logits_batch_stride, const int32_t* labels,
+                                const int32_t* in_len, const int32_t* lab_len, int B, int maxT, int maxU1, int V,
+                                int blank, float* costs, void* workspace, void* hip_stream);
+int rnnt_mi355x_backward_strided(const float* logits, size_t logits_batch_stride, float* grad,
+                                 size_t grad_batch_stride, const int32_t* labels, const int32_t* in_len,
+                                 const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
+                                 const float* grad_scale, void* workspace, void* hip_stream);
+
 /* forward + backward_inplace in one call: what one training step of
  * reference rnnt/train.py:151-157 spends in the loss layer. */
 int rnnt_mi355x_loss_grad(float* logits_inout, const int32_t* labels, const int32_t* in_len, const int32_t* lab_len,

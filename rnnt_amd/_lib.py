@@ -30,6 +30,8 @@ _SIGNATURES = {
     "rnnt_mi355x_workspace_bytes": (ctypes.c_int, [_i, _i, _i, ctypes.POINTER(_sz)]),
     "rnnt_mi355x_forward": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp]),
     "rnnt_mi355x_backward": (ctypes.c_int, [_vp] * 5 + _META + [_vp, _vp, _vp]),
+    "rnnt_mi355x_forward_strided": (ctypes.c_int, [_vp, _sz] + [_vp] * 3 + _META + [_vp, _vp, _vp]),
+    "rnnt_mi355x_backward_strided": (ctypes.c_int, [_vp, _sz, _vp, _sz] + [_vp] * 3 + _META + [_vp, _vp, _vp]),
     "rnnt_mi355x_backward_inplace": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp]),
     "rnnt_mi355x_loss_grad": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp]),
     "rnnt_mi355x_loss_grad_events": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp, _vp, _vp]),

@@ -111,6 +111,8 @@ struct RowGeom {
   int nTB;    // frame blocks per utterance
   int npass;  // passes of NC chunks per lane over one row
   int b0;     // first utterance of this launch
+  size_t xstride;   // elements between consecutive utterances of the logits (>= maxT*maxU1*V)
+  size_t gstride;   // same for the gradient buffer
   int nblocks;      // blocks of this launch = (utterances of this launch) * nTB
   int nblocks_all;  // blocks of the whole batch = B * nTB
 };
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(kRowBlock) void k_lse(const float* __restrict__ x, 
   const int V = gm.V, blank = gm.blank, maxU1 = gm.maxU1, npass = gm.npass;
   const int nchunk = V / VEC;
   const int sq = S / maxU1, sr = S % maxU1;
-  const float* xblk = x + (size_t)(b * gm.maxT + t0) * maxU1 * V;
+  const float* xblk = x + (size_t)b * gm.xstride + (size_t)t0 * maxU1 * V;
   extern __shared__ float4 recs[];  // this block's records, written out in one coalesced burst at the end
 
   for (int i = threadIdx.x; i < rows_blk; i += kRowBlock) recs[i] = make_float4(kNegF, kNegF, 0.f, 0.f);
@@ -588,9 +590,8 @@ __global__ __launch_bounds__(kRowBlock) void k_grad(const float* x, float* grad,
   const int ntiles = ((rows_blk + S - 1) / S) * npass;
   const int nchunk = V / VEC;
   const int sq = S / maxU1, sr = S % maxU1;
-  const size_t blk_row0 = (size_t)(b * gm.maxT + t0) * maxU1;
-  const float* xblk = x + blk_row0 * V;
-  float* gblk = grad + blk_row0 * V;
+  const float* xblk = x + (size_t)b * gm.xstride + (size_t)t0 * maxU1 * V;
+  float* gblk = grad + (size_t)b * gm.gstride + (size_t)t0 * maxU1 * V;
   const float sc = grad_scale ? grad_scale[b] : 1.f;
   int T, U;
   utt_dims(in_len, lab_len, b, gm.maxT, maxU1, T, U);
@@ -1163,6 +1164,7 @@ RowCfg pick_row_cfg(int B, int maxT, int maxU1, int V, int blank, const void* p0
   c.gm.nTB = (maxT + TT - 1) / TT;
   c.gm.npass = (cpl + c.nc - 1) / c.nc;
   c.gm.b0 = 0;
+  c.gm.xstride = c.gm.gstride = (size_t)maxT * maxU1 * V;
   c.gm.nblocks = B * c.gm.nTB;
   c.gm.nblocks_all = B * c.gm.nTB;
   return c;
@@ -1203,13 +1205,18 @@ struct Call {
   const int32_t* in_len;
   const int32_t* lab_len;
   int B, maxT, maxU1, V, blank;
+  size_t xstride, gstride;  // elements between utterances in logits / grad
   const float* grad_scale;
   float* costs;
   Ws w;
 };
 
 RowCfg sub_cfg(const Call& c, const void* p1, int b0, int nb) {
-  RowCfg cfg = pick_row_cfg(c.B, c.maxT, c.maxU1, c.V, c.blank, c.logits, p1);
+  // the widest vector access must also survive the batch strides
+  const uintptr_t align_bits = reinterpret_cast<uintptr_t>(p1) | (uintptr_t)(c.xstride * 4) | (uintptr_t)(c.gstride * 4);
+  RowCfg cfg = pick_row_cfg(c.B, c.maxT, c.maxU1, c.V, c.blank, c.logits, reinterpret_cast<const void*>(align_bits));
+  cfg.gm.xstride = c.xstride;
+  cfg.gm.gstride = c.gstride;
   cfg.gm.b0 = b0;
   cfg.gm.nblocks = nb * cfg.gm.nTB;
   return cfg;
@@ -1218,7 +1225,8 @@ RowCfg sub_cfg(const Call& c, const void* p1, int b0, int nb) {
 // Small-vocabulary path: V <= 64 and 16-byte aligned buffers (a tile of 64 rows is then a whole number of float4).
 bool use_small(const Call& c, const void* p1) {
   const uintptr_t a = reinterpret_cast<uintptr_t>(c.logits) | reinterpret_cast<uintptr_t>(p1);
-  return c.V <= kSmallMaxV && a % 16 == 0;
+  const size_t dense = (size_t)c.maxT * c.maxU1 * c.V;  // its tiles run across utterance boundaries
+  return c.V <= kSmallMaxV && a % 16 == 0 && c.xstride == dense && c.gstride == dense;
 }
 
 SmallGeom small_geom(const Call& c, int* blocks) {
@@ -1309,9 +1317,13 @@ int launch_loss_grad(const Call& c, hipStream_t st, hipEvent_t ev_begin, hipEven
 
 int make_call(Call* c, const float* logits, float* grad, const int32_t* labels, const int32_t* in_len,
               const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank, const float* grad_scale,
-              float* costs, void* workspace, bool need_grad, bool need_costs) {
+              float* costs, void* workspace, bool need_grad, bool need_costs, size_t xstride = 0, size_t gstride = 0) {
   const int rc = check_shape(B, maxT, maxU1, V, blank);
   if (rc != RNNT_MI355X_OK) return rc;
+  const size_t dense = (size_t)maxT * maxU1 * V;
+  if ((xstride && xstride < dense) || (gstride && gstride < dense)) return RNNT_MI355X_INVALID_VALUE;
+  c->xstride = xstride ? xstride : dense;
+  c->gstride = gstride ? gstride : dense;
   if (!logits || !in_len || !lab_len || !workspace || (maxU1 > 1 && !labels)) return RNNT_MI355X_INVALID_VALUE;
   if ((need_grad && !grad) || (need_costs && !costs)) return RNNT_MI355X_INVALID_VALUE;
   c->logits = logits; c->grad = grad; c->labels = labels; c->in_len = in_len; c->lab_len = lab_len;
@@ -1362,6 +1374,27 @@ int rnnt_mi355x_backward(const float* logits, float* grad, const int32_t* labels
   Call c;
   const int rc = make_call(&c, logits, grad, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale, nullptr,
                            workspace, true, false);
+  if (rc != RNNT_MI355X_OK) return rc;
+  return launch_backward(c, static_cast<hipStream_t>(hip_stream));
+}
+
+int rnnt_mi355x_forward_strided(const float* logits, size_t logits_batch_stride, const int32_t* labels,
+                                const int32_t* in_len, const int32_t* lab_len, int B, int maxT, int maxU1, int V,
+                                int blank, float* costs, void* workspace, void* hip_stream) {
+  Call c;
+  const int rc = make_call(&c, logits, nullptr, labels, in_len, lab_len, B, maxT, maxU1, V, blank, nullptr, costs,
+                           workspace, false, true, logits_batch_stride, 0);
+  if (rc != RNNT_MI355X_OK) return rc;
+  return launch_forward(c, static_cast<hipStream_t>(hip_stream));
+}
+
+int rnnt_mi355x_backward_strided(const float* logits, size_t logits_batch_stride, float* grad,
+                                 size_t grad_batch_stride, const int32_t* labels, const int32_t* in_len,
+                                 const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
+                                 const float* grad_scale, void* workspace, void* hip_stream) {
+  Call c;
+  const int rc = make_call(&c, logits, grad, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale, nullptr,
+                           workspace, true, false, logits_batch_stride, grad_batch_stride);
   if (rc != RNNT_MI355X_OK) return rc;
   return launch_backward(c, static_cast<hipStream_t>(hip_stream));
 }

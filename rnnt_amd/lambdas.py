@@ -34,14 +34,13 @@ def rnnt_lambda_func(args, blank_label=REFERENCE_BLANK_LABEL):
 
 def rnnt_lambda_func_v2(args, blank_label=REFERENCE_BLANK_LABEL):
     """[acts[B,T0,U+1,V], labels[B,U], input_length[B,1], label_length[B,1]] -> costs[B]
-    (reference util.py:53-74); acts comes from the FC joint."""
+    (reference util.py:53-74); acts comes from the FC joint.  The crop
+    ``acts[:, 2:, :, :]`` (util.py:63) is not materialised: the loss is told to
+    start at frame 2 (a strided view of the same storage)."""
     acts, labels, input_length, label_length = args
     batch_size = acts.shape[0]                           # util.py:58
-    acts = acts[:, SHIFT:, :, :]                         # util.py:63
     input_length = input_length - SHIFT                  # util.py:64
     input_length = input_length.reshape(batch_size)      # util.py:67
     label_length = label_length.reshape(batch_size)      # util.py:68
-    cropped = acts.contiguous()                          # the crop is a strided view: one copy, then ours to overwrite
-    costs = rnnt_loss(cropped, labels, input_length, label_length, blank_label,
-                      inplace=cropped.data_ptr() != acts.data_ptr())  # util.py:70-72
+    costs = rnnt_loss(acts, labels, input_length, label_length, blank_label, t_offset=SHIFT)  # util.py:63, 70-72
     return costs.reshape(batch_size)                     # util.py:74

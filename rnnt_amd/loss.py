@@ -78,41 +78,65 @@ def _raise_on_flags(ws, device):
     _lib.check(rc, "rnnt_mi355x_read_status")
 
 
+def _batch_strided(t):
+    """True when utterances are whole [T, U+1, V] contiguous blocks laid out with
+    an arbitrary batch stride (a contiguous tensor, or a crop along T of one)."""
+    B, T, U1, V = t.shape
+    st = t.stride()
+    return st[3] == 1 and st[2] == V and st[1] == U1 * V and (B == 1 or st[0] >= T * U1 * V)
+
+
 class _RNNTLossFn(torch.autograd.Function):
+    """acts_full is [B, T0, U+1, V]; the loss sees frames t_offset.. of it (the
+    reference's `acts[:, shift:, :, :]`, util.py:63) without a copy: the kernels
+    are given the address of frame t_offset and the uncropped batch stride."""
+
     @staticmethod
-    def forward(ctx, acts, labels, il, ll, blank, inplace, check_inputs):
-        B, T, U1, V = acts.shape
-        dev = acts.device
+    def forward(ctx, acts_full, labels, il, ll, blank, inplace, check_inputs, t_offset):
+        B, T0, U1, V = acts_full.shape
+        T = T0 - t_offset
+        view = acts_full[:, t_offset:]
+        dev = acts_full.device
+        bstride = view.stride(0) if B > 1 else T * U1 * V
         with torch.cuda.device(dev):
             ws = _workspace(B, T, U1, dev)
             costs = torch.empty(B, dtype=torch.float32, device=dev)
-            rc = _lib.lib().rnnt_mi355x_forward(_ptr(acts), _ptr(labels), _ptr(il), _ptr(ll), B, T, U1, V, blank,
-                                                _ptr(costs), _ptr(ws), _stream_ptr(dev))
-            _lib.check(rc, "rnnt_mi355x_forward")
+            rc = _lib.lib().rnnt_mi355x_forward_strided(_ptr(view), bstride, _ptr(labels), _ptr(il), _ptr(ll), B, T, U1,
+                                                        V, blank, _ptr(costs), _ptr(ws), _stream_ptr(dev))
+            _lib.check(rc, "rnnt_mi355x_forward_strided")
             if check_inputs:
                 _raise_on_flags(ws, dev)
-        ctx.acts, ctx.labels, ctx.il, ctx.ll, ctx.ws = acts, labels, il, ll, ws
-        ctx.blank, ctx.inplace = blank, inplace
+        ctx.acts, ctx.labels, ctx.il, ctx.ll, ctx.ws = acts_full, labels, il, ll, ws
+        ctx.blank, ctx.inplace, ctx.t_offset = blank, inplace, t_offset
         return costs
 
     @staticmethod
     def backward(ctx, grad_costs):
-        acts = ctx.acts
-        if acts is None:
+        acts_full = ctx.acts
+        if acts_full is None:
             raise RuntimeError("rnnt_loss: backward called twice (the lattice state was released)")
-        B, T, U1, V = acts.shape
-        dev = acts.device
+        B, T0, U1, V = acts_full.shape
+        t_offset = ctx.t_offset
+        T = T0 - t_offset
+        dev = acts_full.device
         with torch.cuda.device(dev):
             scale = grad_costs.to(device=dev, dtype=torch.float32).reshape(B).contiguous()
-            grad = acts if ctx.inplace else torch.empty_like(acts)
-            rc = _lib.lib().rnnt_mi355x_backward(_ptr(acts), _ptr(grad), _ptr(ctx.labels), _ptr(ctx.il), _ptr(ctx.ll),
-                                                 B, T, U1, V, ctx.blank, _ptr(scale), _ptr(ctx.ws), _stream_ptr(dev))
-            _lib.check(rc, "rnnt_mi355x_backward")
+            grad_full = acts_full if ctx.inplace else torch.empty(acts_full.shape, dtype=torch.float32, device=dev)
+            view, gview = acts_full[:, t_offset:], grad_full[:, t_offset:]
+            xs = view.stride(0) if B > 1 else T * U1 * V
+            gs = gview.stride(0) if B > 1 else T * U1 * V
+            rc = _lib.lib().rnnt_mi355x_backward_strided(_ptr(view), xs, _ptr(gview), gs, _ptr(ctx.labels), _ptr(ctx.il),
+                                                         _ptr(ctx.ll), B, T, U1, V, ctx.blank, _ptr(scale), _ptr(ctx.ws),
+                                                         _stream_ptr(dev))
+            _lib.check(rc, "rnnt_mi355x_backward_strided")
+            if t_offset:
+                grad_full[:, :t_offset].zero_()  # the cropped frames take no part in the loss
         ctx.acts = ctx.ws = None
-        return grad, None, None, None, None, None, None
+        return grad_full, None, None, None, None, None, None, None
 
 
-def rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0, *, inplace=False, check_inputs=True):
+def rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0, *, inplace=False, check_inputs=True,
+              t_offset=0):
     """Per-utterance transducer costs ``[B]``; same positional signature as the
     ``rnnt_loss`` the reference imports (reference rnnt/base/util.py:70-72,
     113-115), differentiable w.r.t. ``acts`` only.
@@ -122,15 +146,23 @@ def rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0, *, inpl
     gradients are identical, and the returned gradient is always the one with
     respect to the tensor passed in.
 
+    t_offset=k makes the loss see ``acts[:, k:]`` (``input_lengths`` then counts
+    frames of that crop) without copying: the reference's ``shift = 2`` crop
+    (util.py:62-64).  The gradient of the skipped frames is zero.
     inplace=True lets backward overwrite ``acts`` with its gradient (saves a
     [B,T,U+1,V] allocation); only legal when nothing else reads ``acts`` later.
     check_inputs=True reads a 4-byte validation word back after the forward
     (one stream sync) and raises ValueError on malformed lengths/labels.
     """
-    labels, il, ll, blank = _prepare(acts, labels, input_lengths, label_lengths, blank_label)
-    if not acts.is_contiguous():
-        acts = acts.contiguous()
-    return _RNNTLossFn.apply(acts, labels, il, ll, blank, bool(inplace), bool(check_inputs))
+    t_offset = int(t_offset)
+    if not isinstance(acts, torch.Tensor) or acts.dim() != 4 or not 0 <= t_offset < acts.shape[1]:
+        raise ValueError("acts must be a [B, T, U+1, V] tensor and 0 <= t_offset < T")
+    cropped = acts[:, t_offset:]
+    labels, il, ll, blank = _prepare(cropped, labels, input_lengths, label_lengths, blank_label)
+    if not _batch_strided(acts):
+        acts = acts.contiguous()  # a differentiable copy that nobody else reads: backward may overwrite it
+        inplace = True
+    return _RNNTLossFn.apply(acts, labels, il, ll, blank, bool(inplace), bool(check_inputs), t_offset)
 
 
 def rnnt_loss_grad_(acts, labels, input_lengths, label_lengths, blank_label=0, grad_scale=None, *, workspace=None,

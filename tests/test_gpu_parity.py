@@ -211,3 +211,48 @@ def test_unaligned_base_pointer_falls_back_to_narrower_loads():
         assert run.loss_grad() == 0
         torch.cuda.synchronize()
         assert np.abs(view.cpu().numpy() - go).max() < GRAD_ATOL_TIGHT
+
+
+@pytest.mark.parametrize("V,blank", [(1024, 1023), (62, 39), (40, 39)])
+def test_batch_strided_entry_points(V, blank):
+    """rnnt_mi355x_forward_strided / backward_strided on a crop along T of a larger
+    tensor (utterances T0*U1*V elements apart), in place and out of place."""
+    import ctypes
+    from rnnt_amd import _lib
+    B, T0, U, shift = 3, 11, 4, 2
+    T = T0 - shift
+    rng = np.random.default_rng(V)
+    full = rng.standard_normal((B, T0, U + 1, V)).astype(np.float32)
+    lab = rng.integers(0, min(V - 1, 39), (B, U)).astype(np.int32)
+    il = np.array([T, T - 3, 1], np.int32)
+    ll = np.array([U, 2, 0], np.int32)
+    gs = np.array([1.0, 0.5, 2.0], np.float32)
+    co, go = orc.rnnt_loss_and_grad(full[:, shift:], lab, il, ll, blank, gs)
+    dev = torch.device("cuda:0")
+    t_full = torch.from_numpy(full).to(dev)
+    view = t_full[:, shift:]
+    run = HipRun(full[:, shift:], lab, il, ll, blank, gs)          # only for its helper buffers (labels, lengths, ws)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    L = _lib.lib()
+    stride = T0 * (U + 1) * V
+    rc = L.rnnt_mi355x_forward_strided(p(view), stride, p(run.lab), p(run.il), p(run.ll), B, T, U + 1, V, blank,
+                                       p(run.costs), p(run.ws), run.stream)
+    assert rc == 0
+    out = torch.full((B, T, U + 1, V), float("nan"), device=dev)
+    rc = L.rnnt_mi355x_backward_strided(p(view), stride, p(out), T * (U + 1) * V, p(run.lab), p(run.il), p(run.ll),
+                                        B, T, U + 1, V, blank, p(run.gs), p(run.ws), run.stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(run.costs.cpu().numpy(), co, rtol=COST_RTOL)
+    assert np.abs(out.cpu().numpy() - go).max() < GRAD_ATOL_TIGHT
+    assert torch.equal(t_full.cpu(), torch.from_numpy(full))       # logits untouched so far
+    rc = L.rnnt_mi355x_backward_strided(p(view), stride, p(view), stride, p(run.lab), p(run.il), p(run.ll),
+                                        B, T, U + 1, V, blank, p(run.gs), p(run.ws), run.stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = t_full.cpu().numpy()
+    assert np.abs(got[:, shift:] - go).max() < GRAD_ATOL_TIGHT
+    assert np.array_equal(got[:, :shift], full[:, :shift])        # frames outside the crop are never written
+    # a stride smaller than one utterance is rejected
+    assert L.rnnt_mi355x_forward_strided(p(view), T * (U + 1) * V - 1, p(run.lab), p(run.il), p(run.ll), B, T, U + 1,
+                                         V, blank, p(run.costs), p(run.ws), run.stream) == _lib.INVALID_VALUE

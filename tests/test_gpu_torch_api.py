@@ -150,3 +150,32 @@ def test_sharded_run_equals_unsharded():
                 assert torch.equal(c[k], ref_costs[i])
                 assert torch.equal(a[k, : il[i], : ll[i] + 1], ref_grad[i, : il[i], : ll[i] + 1])
         np.testing.assert_allclose(total, ref_s, rtol=1e-6)
+
+
+def test_t_offset_crop_without_copy_matches_explicit_crop():
+    """rnnt_loss(acts, ..., t_offset=2) == rnnt_loss(acts[:, 2:].contiguous(), ...) and the skipped
+    frames get a zero gradient (the crop of reference util.py:62-64)."""
+    for V, blank in ((256, 255), (62, 39)):   # generic kernels and the small-vocabulary path (falls back: strided)
+        x, lab, il, ll = make_batch(3, 13, 5, V, blank, seed=V)
+        il = np.maximum(il - 2, 1).astype(np.int32)
+        a = torch.from_numpy(x).to(DEV).requires_grad_(True)
+        costs = rnnt_amd.rnnt_loss(a, lab, il, ll, blank, t_offset=2)
+        costs.sum().backward()
+        co, go = orc.rnnt_loss_and_grad(x[:, 2:], lab, il, ll, blank)
+        np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+        g = a.grad.cpu().numpy()
+        assert not g[:, :2].any()
+        assert np.abs(g[:, 2:] - go).max() < GRAD_ATOL
+        assert torch.equal(a.detach().cpu(), torch.from_numpy(x))
+
+
+def test_non_contiguous_acts_are_accepted():
+    x, lab, il, ll = make_batch(2, 7, 3, 24, 23, seed=2)
+    base = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1, 3))).to(DEV).requires_grad_(True)  # [B,U1,T,V]
+    acts = base.permute(0, 2, 1, 3)                                                                      # view [B,T,U1,V]
+    assert not acts.is_contiguous()
+    costs = rnnt_amd.rnnt_loss(acts, lab, il, ll, 23)
+    costs.sum().backward()
+    co, go = orc.rnnt_loss_and_grad(x, lab, il, ll, 23)
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+    assert np.abs(base.grad.permute(0, 2, 1, 3).cpu().numpy() - go).max() < GRAD_ATOL
