@@ -115,6 +115,27 @@ int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, con
                                  const float* grad_scale, float* costs, void* workspace, void* hip_stream,
                                  void* ev_grad_begin, void* ev_grad_end);
 
+/* ---- fused additive joint ------------------------------------------------
+ * The loss of the reference's additive-joint model, Util.rnnt_lambda_func
+ * (reference rnnt/base/util.py:107-115): acts = log_softmax(y_trans[B,T,1,V] +
+ * y_pred[B,1,U+1,V]) followed by rnnt_loss(acts, ...), WITHOUT forming the
+ * [B,T,U+1,V] tensor.  f = y_trans [B,maxT,V] (utterances f_batch_stride
+ * elements apart, >= maxT*V: pass the address of frame 2 and the uncropped
+ * stride for the crop of util.py:101), g = y_pred [B,maxU1,V] contiguous.
+ * The backward writes d(sum_b grad_scale[b]*cost_b)/df and /dg directly (what
+ * TensorFlow obtains by reducing the [B,T,U+1,V] gradient over u and over t,
+ * util.py:107-109).  Needs the larger workspace of
+ * rnnt_mi355x_joint_workspace_bytes; V <= 4096.  rnnt_mi355x_reduce_scalars
+ * after a joint backward returns the cost sum and 0 for the norm. */
+int rnnt_mi355x_joint_workspace_bytes(int B, int maxT, int maxU1, size_t* out_bytes);
+int rnnt_mi355x_joint_forward(const float* f, size_t f_batch_stride, const float* g, const int32_t* labels,
+                              const int32_t* in_len, const int32_t* lab_len, int B, int maxT, int maxU1, int V,
+                              int blank, float* costs, void* workspace, void* hip_stream);
+int rnnt_mi355x_joint_backward(const float* f, size_t f_batch_stride, const float* g, const int32_t* labels,
+                               const int32_t* in_len, const int32_t* lab_len, int B, int maxT, int maxU1, int V,
+                               int blank, const float* grad_scale, float* df, size_t df_batch_stride, float* dg,
+                               void* workspace, void* hip_stream);
+
 /* out2[0] = sum_b costs[b], out2[1] = sum of squared gradient elements of the
  * last backward on this workspace (both float64, device memory).  These are
  * the two scalars a data-parallel caller all-reduces: the batch loss of

@@ -60,6 +60,10 @@ struct Ws {
   float4* rec;
   double* alpha;   // [B][D][U1s]
   double* beta;    // [B][D][U1s]
+  // fused additive joint only:
+  float* mf2;      // [B][maxT]  max_v f(b,t,v) * log2(e)
+  float* mg2;      // [B][maxU1] max_v g(b,u,v) * log2(e)
+  float4* coef;    // [B][maxT][maxU1] {c, pb, pl, label as int bits} per cell (c = -inf: no gradient)
   size_t partial_off;
   int D;    // diagonals = maxT + maxU1 - 1
   int U1s;  // row stride = 64 * sweep_cols_per_lane(maxU1)
@@ -73,7 +77,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int sweep_cols_per_lane(int maxU1) { return maxU1 <= 64 ? 1 : maxU1 <= 128 ? 2 : maxU1 <= 256 ? 4 : 8; }
 
 // Lays the workspace out; returns total bytes.  base may be null (size query).
-size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w) {
+size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = false) {
   const int D = maxT + maxU1 - 1;
   const int U1s = 64 * sweep_cols_per_lane(maxU1);
   const size_t plane = (size_t)B * D * U1s;
@@ -90,6 +94,9 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w) {
   const size_t o_rec = take(sizeof(float4) * (size_t)B * (maxT + 2) * maxU1);
   const size_t o_alpha = take(sizeof(double) * plane);
   const size_t o_beta = take(sizeof(double) * plane);
+  const size_t o_mf2 = joint ? take(sizeof(float) * (size_t)B * maxT) : 0;
+  const size_t o_mg2 = joint ? take(sizeof(float) * (size_t)B * maxU1) : 0;
+  const size_t o_coef = joint ? take(sizeof(float4) * (size_t)B * maxT * maxU1) : 0;
   if (w) {
     w->hdr = reinterpret_cast<Header*>(p + o_hdr);
     w->ll = reinterpret_cast<double*>(p + o_ll);
@@ -97,6 +104,9 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w) {
     w->rec = reinterpret_cast<float4*>(p + o_rec);
     w->alpha = reinterpret_cast<double*>(p + o_alpha);
     w->beta = reinterpret_cast<double*>(p + o_beta);
+    w->mf2 = joint ? reinterpret_cast<float*>(p + o_mf2) : nullptr;
+    w->mg2 = joint ? reinterpret_cast<float*>(p + o_mg2) : nullptr;
+    w->coef = joint ? reinterpret_cast<float4*>(p + o_coef) : nullptr;
     w->partial_off = o_partial;
     w->D = D;
     w->U1s = U1s;
@@ -1095,6 +1105,324 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
   }
 }
 
+// ---------------------------------------------------------------------------
+// Fused additive joint (reference Util.rnnt_lambda_func, rnnt/base/util.py:
+// 107-109: acts = log_softmax(y_trans[B,T,1,V] + y_pred[B,1,U+1,V])).  The
+// [B,T,U+1,V] tensor is never formed: with f = y_trans, g = y_pred,
+//   lse(t,u)   = mf(t) + mg(u) + log sum_v exp(f(t,v)-mf(t) + g(u,v)-mg(u))
+//   d f(t,v)   = sum_u dx(t,u,v),   d g(u,v) = sum_t dx(t,u,v)
+// so HBM traffic falls from O(T*U*V) to O((T+U)*V) and the work becomes
+// exp-throughput bound.  Lanes own the vocabulary entries v = lane + 64k; a
+// wavefront keeps a few rows of one operand in registers and streams the rows
+// of the other one past them (they are L2-resident).
+//   k_joint_prep   row maxima mf2, mg2 (base-2)
+//   k_joint_lse    records {lpb, lpl, log2 s} of every cell  (then k_sweep as usual)
+//   k_joint_coef   {c, pb, pl, label} of every cell from alpha, beta, ll
+//   k_joint_grad_f d f: a wave owns TT frames, loops over u
+//   k_joint_grad_g d g: a wave owns UU columns, loops over t   (recomputes the exponentials: no atomics)
+// ---------------------------------------------------------------------------
+struct JointGeom {
+  int B, maxT, maxU1, V, blank;
+  size_t fstride;  // elements between utterances of f (>= maxT*V): lets f be a crop along T of a larger tensor
+  size_t dfstride; // same for d f
+};
+
+// out[k] = row[lane+64k]*log2(e) - m2, or -inf past the end of the row
+template <int KE>
+__device__ __forceinline__ void jrow_load(const float* row, int V, int lane, float m2, float (&out)[KE]) {
+#pragma unroll
+  for (int k = 0; k < KE; ++k) {
+    const int v = lane + 64 * k;
+    out[k] = v < V ? __builtin_fmaf(row[v], kLog2e, -m2) : -INFINITY;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f, const float* __restrict__ g,
+                                                    JointGeom jg, Ws w) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nf = jg.B * jg.maxT, ng = jg.B * jg.maxU1;
+  if (row >= nf + ng) return;
+  const float* p;
+  if (row < nf) {
+    const int b = row / jg.maxT, t = row - b * jg.maxT;
+    p = f + (size_t)b * jg.fstride + (size_t)t * jg.V;
+  } else {
+    p = g + (size_t)(row - nf) * jg.V;
+  }
+  float m = -INFINITY;
+  for (int v = lane; v < jg.V; v += 64) m = fmaxf(m, p[v]);
+  m = group_max<64>(m);
+  if (lane == 0) {
+    if (row < nf) w.mf2[row] = m * kLog2e;
+    else w.mg2[row - nf] = m * kLog2e;
+  }
+}
+
+template <int KE, int TT>
+__global__ __launch_bounds__(256) void k_joint_lse(const float* __restrict__ f, const float* __restrict__ g,
+                                                   const int32_t* __restrict__ labels,
+                                                   const int32_t* __restrict__ in_len,
+                                                   const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
+  extern __shared__ float4 jrecs[];  // [4 waves][TT][maxU1]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ntile = (jg.maxT + TT - 1) / TT;                 // frame tiles per utterance
+  const int tiles_per_blk = 4;
+  const int blocks_per_b = (ntile + tiles_per_blk - 1) / tiles_per_blk;
+  const int b = blockIdx.x / blocks_per_b;
+  const int tile = (blockIdx.x - b * blocks_per_b) * tiles_per_blk + wv;
+  if (tile >= ntile) return;
+  const int t0 = tile * TT;
+  const int V = jg.V, maxU1 = jg.maxU1, blank = jg.blank;
+  int T, U;
+  utt_dims(in_len, lab_len, b, jg.maxT, maxU1, T, U);
+  float4* my = jrecs + (size_t)wv * TT * maxU1;
+  const float4 neg = make_float4(kNegF, kNegF, 0.f, 0.f);
+  for (int i = lane; i < TT * maxU1; i += 64) my[i] = neg;
+
+  const int nt = min(TT, max(T - t0, 0));  // frames of this tile that hold cells
+  if (nt > 0) {
+    float f2[TT][KE];
+    float fb2[TT];
+    const float* frow[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int t = min(t0 + tt, jg.maxT - 1);
+      frow[tt] = f + (size_t)b * jg.fstride + (size_t)t * V;
+      const float m2 = w.mf2[b * jg.maxT + t];
+      jrow_load<KE>(frow[tt], V, lane, m2, f2[tt]);
+      fb2[tt] = __builtin_fmaf(frow[tt][blank], kLog2e, -m2);
+    }
+    const float* gb = g + (size_t)b * maxU1 * V;
+    float g2[KE], g2n[KE];
+    jrow_load<KE>(gb, V, lane, w.mg2[b * maxU1], g2);
+    for (int u = 0; u <= U; ++u) {
+      const float mg2 = w.mg2[b * maxU1 + u];
+      const float* grow = gb + (size_t)u * V;
+      if (u < U) jrow_load<KE>(grow + V, V, lane, w.mg2[b * maxU1 + u + 1], g2n);
+      const float gb2 = __builtin_fmaf(grow[blank], kLog2e, -mg2);
+      int lab = 0;
+      float gl2 = 0.f;
+      if (u < U) {
+        lab = labels[(size_t)b * (maxU1 - 1) + u];
+        if (lab < 0 || lab >= V) {
+          if (lane == 0) atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
+          lab = 0;
+        }
+        gl2 = __builtin_fmaf(grow[lab], kLog2e, -mg2);
+      }
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        if (tt < nt) {
+          // sum_v 2^(f2+g2): every term <= 1 because the row maxima were subtracted
+          float s = 0.f;
+#pragma unroll
+          for (int k = 0; k < KE; ++k) s += fast_exp2(f2[tt][k] + g2[k]);
+          s = group_sum<64>(s);
+          float ls = fast_log2(s);
+          if (!(s > 1e-30f)) {
+            // the maxima of f and g sit at different v and every product underflowed: redo with the exact maximum
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KE; ++k) m = fmaxf(m, f2[tt][k] + g2[k]);
+            m = group_max<64>(m);
+            float s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < KE; ++k) s2 += fast_exp2(f2[tt][k] + g2[k] - m);
+            s2 = group_sum<64>(s2);
+            ls = m + fast_log2(s2);
+          }
+          if (lane == 0) {
+            const float m2 = w.mf2[b * jg.maxT + t0 + tt];
+            const float fl2 = (u < U) ? __builtin_fmaf(frow[tt][lab], kLog2e, -m2) : 0.f;
+            my[tt * maxU1 + u] = make_float4(fb2[tt] + gb2 - ls, (u < U) ? fl2 + gl2 - ls : kNegF, ls, 0.f);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KE; ++k) g2[k] = g2n[k];
+    }
+  }
+  // records of the tile's frames (log 0 where there is no cell), one contiguous burst per wave
+  float4* frame0 = w.rec + ((size_t)b * (jg.maxT + 2) + 1) * maxU1;
+  const int nfr = min(TT, jg.maxT - t0);
+  float4* out = frame0 + (size_t)t0 * maxU1;
+  for (int i = lane; i < nfr * maxU1; i += 64) out[i] = my[i];
+  if (t0 == 0)
+    for (int i = lane; i < maxU1; i += 64) (frame0 - maxU1)[i] = neg;
+  if (t0 + TT >= jg.maxT)
+    for (int i = lane; i < maxU1; i += 64) (frame0 + (size_t)jg.maxT * maxU1)[i] = neg;
+}
+
+// one thread per (b, t, u): {c, s*pb, s*pl, label}; c = log2 gamma - log2 s_cell, -inf when the cell is pruned
+__global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ labels,
+                                                    const int32_t* __restrict__ in_len,
+                                                    const int32_t* __restrict__ lab_len,
+                                                    const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long n = (long long)jg.B * jg.maxT * jg.maxU1;
+  if (i >= n) return;
+  const int per_b = jg.maxT * jg.maxU1;
+  const int b = (int)(i / per_b);
+  const int rem = (int)(i - (long long)b * per_b);
+  const int t = rem / jg.maxU1, u = rem - t * jg.maxU1;
+  int T, U;
+  utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
+  float4 cf = cell_coef(cell_load(w, labels, b, t, u, T, U, jg.maxT, jg.maxU1, jg.V, true));
+  const float sc = grad_scale ? grad_scale[b] : 1.f;
+  cf.y *= sc;
+  cf.z *= sc;
+  w.coef[i] = cf;
+}
+
+template <int KE, int TT>
+__global__ __launch_bounds__(256) void k_joint_grad_f(const float* __restrict__ f, const float* __restrict__ g,
+                                                      float* __restrict__ df, const int32_t* __restrict__ in_len,
+                                                      const int32_t* __restrict__ lab_len,
+                                                      const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ntile = (jg.maxT + TT - 1) / TT;
+  const int blocks_per_b = (ntile + 3) / 4;
+  const int b = blockIdx.x / blocks_per_b;
+  const int tile = (blockIdx.x - b * blocks_per_b) * 4 + wv;
+  if (tile >= ntile) return;
+  const int t0 = tile * TT;
+  const int V = jg.V, maxU1 = jg.maxU1, blank = jg.blank;
+  int T, U;
+  utt_dims(in_len, lab_len, b, jg.maxT, maxU1, T, U);
+  const float sc = grad_scale ? grad_scale[b] : 1.f;
+  const int nt = min(TT, max(T - t0, 0));
+  float acc[TT][KE];
+  float sumb[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    sumb[tt] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KE; ++k) acc[tt][k] = 0.f;
+  }
+  if (nt > 0) {
+    float f2[TT][KE];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int t = min(t0 + tt, jg.maxT - 1);
+      jrow_load<KE>(f + (size_t)b * jg.fstride + (size_t)t * V, V, lane, w.mf2[b * jg.maxT + t], f2[tt]);
+    }
+    const float* gb = g + (size_t)b * maxU1 * V;
+    const float4* cfb = w.coef + ((size_t)b * jg.maxT + t0) * maxU1;
+    for (int u = 0; u <= U; ++u) {
+      float4 cf[TT];
+      bool any = false;
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        cf[tt] = (tt < nt) ? cfb[(size_t)tt * maxU1 + u] : make_float4(-INFINITY, 0.f, 0.f, 0.f);
+        any |= cf[tt].x > -INFINITY;
+      }
+      if (!any) continue;  // uniform: coefficients are the same in every lane
+      float g2[KE];
+      jrow_load<KE>(gb + (size_t)u * V, V, lane, w.mg2[b * maxU1 + u], g2);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        if (cf[tt].x > -INFINITY) {
+          const int lab = __float_as_int(cf[tt].w);
+          const float c = cf[tt].x, plv = cf[tt].z;
+          sumb[tt] += cf[tt].y;
+#pragma unroll
+          for (int k = 0; k < KE; ++k) {
+            const float e = sc * fast_exp2(f2[tt][k] + g2[k] + c);
+            acc[tt][k] += e - ((lane + 64 * k == lab) ? plv : 0.f);
+          }
+        }
+      }
+    }
+  }
+  // frames at or beyond T_b get zeros
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int t = t0 + tt;
+    if (t < jg.maxT) {
+      float* out = df + (size_t)b * jg.dfstride + (size_t)t * V;
+#pragma unroll
+      for (int k = 0; k < KE; ++k) {
+        const int v = lane + 64 * k;
+        if (v < V) out[v] = acc[tt][k] - ((v == blank) ? sumb[tt] : 0.f);
+      }
+    }
+  }
+}
+
+template <int KE, int UU>
+__global__ __launch_bounds__(256) void k_joint_grad_g(const float* __restrict__ f, const float* __restrict__ g,
+                                                      float* __restrict__ dg, const int32_t* __restrict__ in_len,
+                                                      const int32_t* __restrict__ lab_len,
+                                                      const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ntile = (jg.maxU1 + UU - 1) / UU;
+  const int blocks_per_b = (ntile + 3) / 4;
+  const int b = blockIdx.x / blocks_per_b;
+  const int tile = (blockIdx.x - b * blocks_per_b) * 4 + wv;
+  if (tile >= ntile) return;
+  const int u0 = tile * UU;
+  const int V = jg.V, maxU1 = jg.maxU1, blank = jg.blank;
+  int T, U;
+  utt_dims(in_len, lab_len, b, jg.maxT, maxU1, T, U);
+  const float sc = grad_scale ? grad_scale[b] : 1.f;
+  const int nu = (T > 0) ? min(UU, max(U + 1 - u0, 0)) : 0;  // columns of this tile that hold cells
+  float acc[UU][KE];
+  float sumb[UU], suml[UU];
+  int lab[UU];
+#pragma unroll
+  for (int uu = 0; uu < UU; ++uu) {
+    sumb[uu] = 0.f; suml[uu] = 0.f; lab[uu] = -1;
+#pragma unroll
+    for (int k = 0; k < KE; ++k) acc[uu][k] = 0.f;
+  }
+  if (nu > 0) {
+    float g2[UU][KE];
+#pragma unroll
+    for (int uu = 0; uu < UU; ++uu) {
+      const int u = min(u0 + uu, maxU1 - 1);
+      jrow_load<KE>(g + ((size_t)b * maxU1 + u) * V, V, lane, w.mg2[b * maxU1 + u], g2[uu]);
+    }
+    const float* fb = f + (size_t)b * jg.fstride;
+    const float4* cfb = w.coef + (size_t)b * jg.maxT * maxU1 + u0;
+    for (int t = 0; t < T; ++t) {
+      float4 cf[UU];
+      bool any = false;
+#pragma unroll
+      for (int uu = 0; uu < UU; ++uu) {
+        cf[uu] = (uu < nu) ? cfb[(size_t)t * maxU1 + uu] : make_float4(-INFINITY, 0.f, 0.f, 0.f);
+        any |= cf[uu].x > -INFINITY;
+      }
+      if (!any) continue;
+      float f2[KE];
+      jrow_load<KE>(fb + (size_t)t * V, V, lane, w.mf2[b * jg.maxT + t], f2);
+#pragma unroll
+      for (int uu = 0; uu < UU; ++uu) {
+        if (cf[uu].x > -INFINITY) {
+          const float c = cf[uu].x;
+          sumb[uu] += cf[uu].y;
+          suml[uu] += cf[uu].z;
+          lab[uu] = __float_as_int(cf[uu].w);
+#pragma unroll
+          for (int k = 0; k < KE; ++k) acc[uu][k] += sc * fast_exp2(f2[k] + g2[uu][k] + c);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int uu = 0; uu < UU; ++uu) {
+    const int u = u0 + uu;
+    if (u < maxU1) {
+      float* out = dg + ((size_t)b * maxU1 + u) * V;
+#pragma unroll
+      for (int k = 0; k < KE; ++k) {
+        const int v = lane + 64 * k;
+        if (v < V) out[v] = acc[uu][k] - ((v == blank) ? sumb[uu] : 0.f) - ((v == lab[uu]) ? suml[uu] : 0.f);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void k_init(Ws w, int n_partial) {
   if (threadIdx.x == 0) {
     w.hdr->flags = 0;
@@ -1333,6 +1661,83 @@ int make_call(Call* c, const float* logits, float* grad, const int32_t* labels, 
   return RNNT_MI355X_OK;
 }
 
+// ---- fused additive joint: host side ----
+struct JointCall {
+  const float* f;
+  const float* g;
+  const int32_t* labels;
+  const int32_t* in_len;
+  const int32_t* lab_len;
+  JointGeom jg;
+  Ws w;
+};
+
+int joint_ke(int V) {
+  int ke = 1;
+  while (ke * 64 < V) ke <<= 1;
+  return ke;  // 1..64 for V <= 4096
+}
+
+int make_joint_call(JointCall* c, const float* f, size_t fstride, const float* g, const int32_t* labels,
+                    const int32_t* in_len, const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
+                    size_t dfstride, void* workspace) {
+  const int rc = check_shape(B, maxT, maxU1, V, blank);
+  if (rc != RNNT_MI355X_OK) return rc;
+  if (V > 4096) return RNNT_MI355X_UNSUPPORTED_SIZE;
+  if (!f || !g || !in_len || !lab_len || !workspace || (maxU1 > 1 && !labels)) return RNNT_MI355X_INVALID_VALUE;
+  const size_t dense = (size_t)maxT * V;
+  if ((fstride && fstride < dense) || (dfstride && dfstride < dense)) return RNNT_MI355X_INVALID_VALUE;
+  c->f = f; c->g = g; c->labels = labels; c->in_len = in_len; c->lab_len = lab_len;
+  c->jg.B = B; c->jg.maxT = maxT; c->jg.maxU1 = maxU1; c->jg.V = V; c->jg.blank = blank;
+  c->jg.fstride = fstride ? fstride : dense;
+  c->jg.dfstride = dfstride ? dfstride : dense;
+  ws_layout(workspace, B, maxT, maxU1, &c->w, true);
+  return RNNT_MI355X_OK;
+}
+
+#define RNNT_JOINT_DISPATCH(KERNEL, ke, GRID, LDS, T16, T32, T64, ...)                       \
+  do {                                                                                       \
+    switch (ke) {                                                                            \
+      case 1: KERNEL<1, 4><<<GRID(4), 256, LDS(4), st>>>(__VA_ARGS__); break;                \
+      case 2: KERNEL<2, 4><<<GRID(4), 256, LDS(4), st>>>(__VA_ARGS__); break;                \
+      case 4: KERNEL<4, 4><<<GRID(4), 256, LDS(4), st>>>(__VA_ARGS__); break;                \
+      case 8: KERNEL<8, 4><<<GRID(4), 256, LDS(4), st>>>(__VA_ARGS__); break;                \
+      case 16: KERNEL<16, T16><<<GRID(T16), 256, LDS(T16), st>>>(__VA_ARGS__); break;        \
+      case 32: KERNEL<32, T32><<<GRID(T32), 256, LDS(T32), st>>>(__VA_ARGS__); break;        \
+      default: KERNEL<64, T64><<<GRID(T64), 256, LDS(T64), st>>>(__VA_ARGS__); break;        \
+    }                                                                                        \
+  } while (0)
+
+int launch_joint_forward(const JointCall& c, float* costs, hipStream_t st) {
+  const JointGeom& jg = c.jg;
+  const int ke = joint_ke(jg.V);
+  k_init<<<1, 64, 0, st>>>(c.w, 0);
+  const int rows = jg.B * (jg.maxT + jg.maxU1);
+  k_joint_prep<<<(rows + 3) / 4, 256, 0, st>>>(c.f, c.g, jg, c.w);
+#define JGRID_T(TT) dim3((unsigned)(jg.B * ((((jg.maxT + (TT)-1) / (TT)) + 3) / 4)))
+#define JLDS_T(TT) (sizeof(float4) * 4 * (size_t)(TT) * jg.maxU1)
+  RNNT_JOINT_DISPATCH(k_joint_lse, ke, JGRID_T, JLDS_T, 4, 2, 1, c.f, c.g, c.labels, c.in_len, c.lab_len, jg, c.w);
+  Call sc;  // the lattice sweep is the one of the materialised path
+  sc.in_len = c.in_len; sc.lab_len = c.lab_len; sc.B = jg.B; sc.maxT = jg.maxT; sc.maxU1 = jg.maxU1;
+  sc.costs = costs; sc.w = c.w;
+  launch_sweep(sc, 0, jg.B, st);
+  return launch_status();
+}
+
+int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df, float* dg, hipStream_t st) {
+  const JointGeom& jg = c.jg;
+  const int ke = joint_ke(jg.V);
+  const long long cells = (long long)jg.B * jg.maxT * jg.maxU1;
+  k_joint_coef<<<(unsigned)((cells + 255) / 256), 256, 0, st>>>(c.labels, c.in_len, c.lab_len, grad_scale, jg, c.w);
+#define JLDS_0(TT) 0
+  RNNT_JOINT_DISPATCH(k_joint_grad_f, ke, JGRID_T, JLDS_0, 2, 1, 1, c.f, c.g, df, c.in_len, c.lab_len, grad_scale, jg,
+                      c.w);
+#define JGRID_U(UU) dim3((unsigned)(jg.B * ((((jg.maxU1 + (UU)-1) / (UU)) + 3) / 4)))
+  RNNT_JOINT_DISPATCH(k_joint_grad_g, ke, JGRID_U, JLDS_0, 2, 1, 1, c.f, c.g, dg, c.in_len, c.lab_len, grad_scale, jg,
+                      c.w);
+  return launch_status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1423,6 +1828,37 @@ int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, con
   if (rc != RNNT_MI355X_OK) return rc;
   return launch_loss_grad(c, static_cast<hipStream_t>(hip_stream), static_cast<hipEvent_t>(ev_grad_begin),
                           static_cast<hipEvent_t>(ev_grad_end));
+}
+
+int rnnt_mi355x_joint_workspace_bytes(int B, int maxT, int maxU1, size_t* out_bytes) {
+  if (!out_bytes) return RNNT_MI355X_INVALID_VALUE;
+  const int rc = check_shape(B, maxT, maxU1, 1, 0);
+  if (rc != RNNT_MI355X_OK) return rc;
+  *out_bytes = ws_layout(nullptr, B, maxT, maxU1, nullptr, true);
+  return RNNT_MI355X_OK;
+}
+
+int rnnt_mi355x_joint_forward(const float* f, size_t f_batch_stride, const float* g, const int32_t* labels,
+                              const int32_t* in_len, const int32_t* lab_len, int B, int maxT, int maxU1, int V,
+                              int blank, float* costs, void* workspace, void* hip_stream) {
+  JointCall c;
+  const int rc = make_joint_call(&c, f, f_batch_stride, g, labels, in_len, lab_len, B, maxT, maxU1, V, blank, 0,
+                                 workspace);
+  if (rc != RNNT_MI355X_OK) return rc;
+  if (!costs) return RNNT_MI355X_INVALID_VALUE;
+  return launch_joint_forward(c, costs, static_cast<hipStream_t>(hip_stream));
+}
+
+int rnnt_mi355x_joint_backward(const float* f, size_t f_batch_stride, const float* g, const int32_t* labels,
+                               const int32_t* in_len, const int32_t* lab_len, int B, int maxT, int maxU1, int V,
+                               int blank, const float* grad_scale, float* df, size_t df_batch_stride, float* dg,
+                               void* workspace, void* hip_stream) {
+  JointCall c;
+  const int rc = make_joint_call(&c, f, f_batch_stride, g, labels, in_len, lab_len, B, maxT, maxU1, V, blank,
+                                 df_batch_stride, workspace);
+  if (rc != RNNT_MI355X_OK) return rc;
+  if (!df || !dg) return RNNT_MI355X_INVALID_VALUE;
+  return launch_joint_backward(c, grad_scale, df, dg, static_cast<hipStream_t>(hip_stream));
 }
 
 int rnnt_mi355x_reduce_scalars(const float* costs, int B, void* workspace, double* out2, void* hip_stream) {

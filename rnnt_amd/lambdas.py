@@ -11,22 +11,28 @@ and, through autograd, the same gradients with respect to the lambda inputs.
 """
 from __future__ import annotations
 
-from .loss import rnnt_loss
+from .loss import rnnt_joint_loss, rnnt_loss
 
 SHIFT = 2  # "the first couple outputs of the RNN tend to be garbage" (util.py:60-62, 98-100)
 REFERENCE_BLANK_LABEL = 39  # util.py:72, util.py:115
 
 
-def rnnt_lambda_func(args, blank_label=REFERENCE_BLANK_LABEL):
+def rnnt_lambda_func(args, blank_label=REFERENCE_BLANK_LABEL, fused=True):
     """[y_trans[B,T0,V], y_pred[B,U+1,V], labels[B,U], input_length[B,1], label_length[B,1]] -> costs[B]
-    (reference util.py:93-117)."""
+    (reference util.py:93-117).  fused=True (default) never forms the
+    [B,T,U+1,V] joint of util.py:107-109; fused=False builds it with a broadcast
+    add and calls rnnt_loss on it, exactly as the reference does."""
     y_trans, y_pred, labels, input_length, label_length = args
-    y_trans = y_trans[:, SHIFT:, :]                      # util.py:101
-    input_length = input_length - SHIFT                  # util.py:102 (no in-place edit of the caller's tensor)
     batch_size = y_trans.shape[0]                        # util.py:106
-    acts = y_trans.unsqueeze(2) + y_pred.unsqueeze(1)    # util.py:107-109 (BT1V + B1UV)
+    input_length = input_length - SHIFT                  # util.py:102 (no in-place edit of the caller's tensor)
     input_length = input_length.reshape(batch_size)      # util.py:110
     label_length = label_length.reshape(batch_size)      # util.py:111
+    if fused and y_trans.shape[2] <= 4096:
+        costs = rnnt_joint_loss(y_trans, y_pred, labels, input_length, label_length, blank_label,
+                                t_offset=SHIFT)          # util.py:101, 107-109, 113-115
+        return costs.reshape(batch_size)                 # util.py:117
+    y_trans = y_trans[:, SHIFT:, :]                      # util.py:101
+    acts = y_trans.unsqueeze(2) + y_pred.unsqueeze(1)    # util.py:107-109 (BT1V + B1UV)
     # acts is a fresh temporary nobody else reads: let backward reuse its storage
     costs = rnnt_loss(acts, labels, input_length, label_length, blank_label, inplace=True)  # util.py:113-115
     return costs.reshape(batch_size)                     # util.py:117

@@ -39,7 +39,10 @@ def _prepare(acts, labels, input_lengths, label_lengths, blank_label):
     if acts.dtype != torch.float32:
         raise TypeError("acts must be float32 (reference rnnt/keras_model.py builds float32 graphs)")
     B, T, U1, V = acts.shape
-    dev = acts.device
+    return _prepare_meta(B, T, U1, V, acts.device, labels, input_lengths, label_lengths, blank_label)
+
+
+def _prepare_meta(B, T, U1, V, dev, labels, input_lengths, label_lengths, blank_label):
     labels = torch.as_tensor(labels).to(device=dev, dtype=torch.int32).reshape(B, -1)
     if labels.shape[1] != U1 - 1:
         raise ValueError(f"labels must be [B, U] with U = acts.shape[2]-1 = {U1 - 1}, got {tuple(labels.shape)}")
@@ -163,6 +166,80 @@ def rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0, *, inpl
         acts = acts.contiguous()  # a differentiable copy that nobody else reads: backward may overwrite it
         inplace = True
     return _RNNTLossFn.apply(acts, labels, il, ll, blank, bool(inplace), bool(check_inputs), t_offset)
+
+
+class _RNNTJointLossFn(torch.autograd.Function):
+    """Loss of the additive joint f[B,T0,V] (+) g[B,U+1,V] without forming
+    [B,T,U+1,V]; frames t_offset.. of f take part (crop of util.py:101)."""
+
+    @staticmethod
+    def forward(ctx, f_full, g, labels, il, ll, blank, check_inputs, t_offset):
+        B, T0, V = f_full.shape
+        U1 = g.shape[1]
+        T = T0 - t_offset
+        dev = f_full.device
+        fview = f_full[:, t_offset:]
+        fstride = fview.stride(0) if B > 1 else T * V
+        with torch.cuda.device(dev):
+            ws = torch.empty(_lib.joint_workspace_bytes(B, T, U1), dtype=torch.uint8, device=dev)
+            costs = torch.empty(B, dtype=torch.float32, device=dev)
+            rc = _lib.lib().rnnt_mi355x_joint_forward(_ptr(fview), fstride, _ptr(g), _ptr(labels), _ptr(il), _ptr(ll),
+                                                      B, T, U1, V, blank, _ptr(costs), _ptr(ws), _stream_ptr(dev))
+            _lib.check(rc, "rnnt_mi355x_joint_forward")
+            if check_inputs:
+                _raise_on_flags(ws, dev)
+        ctx.saved = (f_full, g, labels, il, ll, ws)
+        ctx.blank, ctx.t_offset = blank, t_offset
+        return costs
+
+    @staticmethod
+    def backward(ctx, grad_costs):
+        if ctx.saved is None:
+            raise RuntimeError("rnnt_joint_loss: backward called twice (the lattice state was released)")
+        f_full, g, labels, il, ll, ws = ctx.saved
+        B, T0, V = f_full.shape
+        U1 = g.shape[1]
+        t_offset = ctx.t_offset
+        T = T0 - t_offset
+        dev = f_full.device
+        with torch.cuda.device(dev):
+            scale = grad_costs.to(device=dev, dtype=torch.float32).reshape(B).contiguous()
+            df_full = torch.empty(f_full.shape, dtype=torch.float32, device=dev)
+            dg = torch.empty(g.shape, dtype=torch.float32, device=dev)
+            fview, dfview = f_full[:, t_offset:], df_full[:, t_offset:]
+            fs = fview.stride(0) if B > 1 else T * V
+            dfs = dfview.stride(0) if B > 1 else T * V
+            rc = _lib.lib().rnnt_mi355x_joint_backward(_ptr(fview), fs, _ptr(g), _ptr(labels), _ptr(il), _ptr(ll), B, T,
+                                                       U1, V, ctx.blank, _ptr(scale), _ptr(dfview), dfs, _ptr(dg),
+                                                       _ptr(ws), _stream_ptr(dev))
+            _lib.check(rc, "rnnt_mi355x_joint_backward")
+            if t_offset:
+                df_full[:, :t_offset].zero_()
+        ctx.saved = None
+        return df_full, dg, None, None, None, None, None, None
+
+
+def rnnt_joint_loss(f, g, labels, input_lengths, label_lengths, blank_label=0, *, check_inputs=True, t_offset=0):
+    """Costs ``[B]`` of the additive-joint transducer: equal to
+    ``rnnt_loss(f[:, t_offset:, None, :] + g[:, None, :, :], ...)`` (the joint of
+    reference rnnt/base/util.py:107-109) but the ``[B,T,U+1,V]`` tensor is never
+    formed; differentiable w.r.t. ``f`` [B,T0,V] and ``g`` [B,U+1,V]."""
+    t_offset = int(t_offset)
+    if f.dim() != 3 or g.dim() != 3 or f.shape[0] != g.shape[0] or f.shape[2] != g.shape[2]:
+        raise ValueError("f must be [B, T, V] and g [B, U+1, V]")
+    if not (f.is_cuda and g.is_cuda):
+        raise RuntimeError("rnnt_amd.rnnt_joint_loss runs on an AMD GPU only; there is no CPU path")
+    if f.dtype != torch.float32 or g.dtype != torch.float32:
+        raise TypeError("f and g must be float32")
+    if not 0 <= t_offset < f.shape[1]:
+        raise ValueError("0 <= t_offset < T required")
+    B, T0, V = f.shape
+    U1 = g.shape[1]
+    if V > 4096:
+        raise ValueError("rnnt_joint_loss supports V <= 4096")
+    labels, il, ll, blank = _prepare_meta(B, T0 - t_offset, U1, V, f.device, labels, input_lengths, label_lengths,
+                                          blank_label)
+    return _RNNTJointLossFn.apply(f.contiguous(), g.contiguous(), labels, il, ll, blank, bool(check_inputs), t_offset)
 
 
 def rnnt_loss_grad_(acts, labels, input_lengths, label_lengths, blank_label=0, grad_scale=None, *, workspace=None,

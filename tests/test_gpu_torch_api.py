@@ -179,3 +179,75 @@ def test_non_contiguous_acts_are_accepted():
     co, go = orc.rnnt_loss_and_grad(x, lab, il, ll, 23)
     np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
     assert np.abs(base.grad.permute(0, 2, 1, 3).cpu().numpy() - go).max() < GRAD_ATOL
+
+
+JOINT_SHAPES = [  # B, T, U, V, blank -> every elements-per-lane variant of the fused joint kernels
+    (3, 9, 4, 40, 39), (2, 11, 5, 62, 39), (2, 8, 3, 100, 0), (2, 7, 4, 200, 199), (2, 9, 3, 512, 5),
+    (2, 6, 4, 1000, 999), (2, 5, 2, 1024, 1023), (1, 4, 3, 2000, 7), (1, 3, 2, 4096, 4095), (2, 1, 3, 30, 2),
+    (2, 6, 0, 30, 2), (1, 20, 130, 16, 15),
+]
+
+
+@pytest.mark.parametrize("B,T,U,V,blank", JOINT_SHAPES)
+def test_fused_joint_matches_oracle(B, T, U, V, blank):
+    rng = np.random.default_rng(B * 7 + T * 5 + U * 3 + V)
+    f = rng.standard_normal((B, T, V)).astype(np.float32) * 1.5
+    g = rng.standard_normal((B, U + 1, V)).astype(np.float32) * 1.5
+    lab = rng.integers(0, V - 1, (B, U)).astype(np.int32)
+    lab[lab >= blank] += 1
+    il = rng.integers(max(1, T // 2), T + 1, B).astype(np.int32)
+    ll = rng.integers(0, U + 1, B).astype(np.int32)
+    il[0], ll[0] = T, U
+    w = np.linspace(0.5, 1.5, B).astype(np.float32)
+    joint = f[:, :, None, :] + g[:, None, :, :]
+    co, gj = orc.rnnt_loss_and_grad(joint, lab, il, ll, blank, w)
+    tf_ = torch.from_numpy(f).to(DEV).requires_grad_(True)
+    tg = torch.from_numpy(g).to(DEV).requires_grad_(True)
+    costs = rnnt_amd.rnnt_joint_loss(tf_, tg, lab, il, ll, blank)
+    (costs * torch.from_numpy(w).to(DEV)).sum().backward()
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+    # d f = sum over u, d g = sum over t of the joint gradient: up to U+1 (T) terms, each within the 1e-4 bar
+    assert np.abs(tf_.grad.cpu().numpy() - gj.sum(2)).max() < GRAD_ATOL
+    assert np.abs(tg.grad.cpu().numpy() - gj.sum(1)).max() < GRAD_ATOL
+
+
+def test_fused_joint_equals_materialised_path_and_handles_separated_maxima():
+    """f and g peak at different vocabulary entries with a large margin: the sum of
+    products 2^(f-mf)*2^(g-mg) underflows and the exact-maximum fallback must take over."""
+    B, T, U, V, blank = 2, 6, 3, 96, 95
+    rng = np.random.default_rng(4)
+    f = rng.standard_normal((B, T, V)).astype(np.float32)
+    g = rng.standard_normal((B, U + 1, V)).astype(np.float32)
+    f[:, :, 3] += 400.0          # f's maximum
+    g[:, :, 70] += 400.0         # g's maximum elsewhere: products of the two normalised terms vanish
+    lab = rng.integers(0, V - 1, (B, U)).astype(np.int32)
+    il, ll = np.array([T, T - 2], np.int32), np.array([U, 1], np.int32)
+    joint = f[:, :, None, :] + g[:, None, :, :]
+    co, gj = orc.rnnt_loss_and_grad(joint, lab, il, ll, blank)
+    tf_ = torch.from_numpy(f).to(DEV).requires_grad_(True)
+    tg = torch.from_numpy(g).to(DEV).requires_grad_(True)
+    costs = rnnt_amd.rnnt_joint_loss(tf_, tg, lab, il, ll, blank)
+    costs.sum().backward()
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+    assert np.abs(tf_.grad.cpu().numpy() - gj.sum(2)).max() < GRAD_ATOL
+    assert np.abs(tg.grad.cpu().numpy() - gj.sum(1)).max() < GRAD_ATOL
+
+
+def test_lambda_func_fused_and_unfused_agree():
+    rng = np.random.default_rng(15)
+    B, T0, U, V = 3, 16, 6, 62
+    yt = rng.standard_normal((B, T0, V)).astype(np.float32)
+    yp = rng.standard_normal((B, U + 1, V)).astype(np.float32)
+    lab = rng.integers(0, 39, (B, U)).astype(np.int32)
+    il = torch.tensor([[16], [11], [14]], dtype=torch.int32, device=DEV)
+    ll = torch.tensor([[6], [3], [5]], dtype=torch.int32, device=DEV)
+    res = []
+    for fused in (True, False):
+        a = torch.from_numpy(yt).to(DEV).requires_grad_(True)
+        b = torch.from_numpy(yp).to(DEV).requires_grad_(True)
+        c = rnnt_amd.rnnt_lambda_func([a, b, torch.from_numpy(lab).to(DEV), il, ll], fused=fused)
+        c.mean().backward()
+        res.append((c.detach().cpu().numpy(), a.grad.cpu().numpy(), b.grad.cpu().numpy()))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=COST_RTOL)
+    assert np.abs(res[0][1] - res[1][1]).max() < GRAD_ATOL and np.abs(res[0][2] - res[1][2]).max() < GRAD_ATOL
+    assert not res[0][1][:, :2].any()
