@@ -1133,7 +1133,8 @@ __device__ __forceinline__ void jrow_load(const float* row, int V, int lane, flo
 #pragma unroll
   for (int k = 0; k < KE; ++k) {
     const int v = lane + 64 * k;
-    out[k] = v < V ? __builtin_fmaf(row[v], kLog2e, -m2) : -INFINITY;
+    const float x = row[min(v, V - 1)];  // unconditional load (a guarded one costs a branch and a wait per element)
+    out[k] = v < V ? __builtin_fmaf(x, kLog2e, -m2) : -INFINITY;
   }
 }
 
@@ -1159,99 +1160,118 @@ __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f,
   }
 }
 
-template <int KE, int TT>
-__global__ __launch_bounds__(256) void k_joint_lse(const float* __restrict__ f, const float* __restrict__ g,
-                                                   const int32_t* __restrict__ labels,
-                                                   const int32_t* __restrict__ in_len,
-                                                   const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
-  extern __shared__ float4 jrecs[];  // [4 waves][TT][maxU1]
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int ntile = (jg.maxT + TT - 1) / TT;                 // frame tiles per utterance
-  const int tiles_per_blk = 4;
-  const int blocks_per_b = (ntile + tiles_per_blk - 1) / tiles_per_blk;
-  const int b = blockIdx.x / blocks_per_b;
-  const int tile = (blockIdx.x - b * blocks_per_b) * tiles_per_blk + wv;
-  if (tile >= ntile) return;
-  const int t0 = tile * TT;
-  const int V = jg.V, maxU1 = jg.maxU1, blank = jg.blank;
+// One thread per (b, t, u): the part of the cell's record that does not need the sum over V,
+//   {f2(t,blank) + g2(u,blank), f2(t,y_{u+1}) + g2(u,y_{u+1}), 0, 0}   (f2 = f*log2e - mf2, g2 likewise)
+// so that k_joint_lse has no data-dependent address in its loop.  Entries that are no lattice cell get "log 0".
+__global__ __launch_bounds__(256) void k_joint_gather(const float* __restrict__ f, const float* __restrict__ g,
+                                                      const int32_t* __restrict__ labels,
+                                                      const int32_t* __restrict__ in_len,
+                                                      const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int per_b = jg.maxT * jg.maxU1;
+  if (i >= (long long)jg.B * per_b) return;
+  const int b = (int)(i / per_b);
+  const int rem = (int)(i - (long long)b * per_b);
+  const int t = rem / jg.maxU1, u = rem - t * jg.maxU1;
   int T, U;
-  utt_dims(in_len, lab_len, b, jg.maxT, maxU1, T, U);
-  float4* my = jrecs + (size_t)wv * TT * maxU1;
-  const float4 neg = make_float4(kNegF, kNegF, 0.f, 0.f);
-  for (int i = lane; i < TT * maxU1; i += 64) my[i] = neg;
-
-  const int nt = min(TT, max(T - t0, 0));  // frames of this tile that hold cells
-  if (nt > 0) {
-    float f2[TT][KE];
-    float fb2[TT];
-    const float* frow[TT];
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-      const int t = min(t0 + tt, jg.maxT - 1);
-      frow[tt] = f + (size_t)b * jg.fstride + (size_t)t * V;
-      const float m2 = w.mf2[b * jg.maxT + t];
-      jrow_load<KE>(frow[tt], V, lane, m2, f2[tt]);
-      fb2[tt] = __builtin_fmaf(frow[tt][blank], kLog2e, -m2);
-    }
-    const float* gb = g + (size_t)b * maxU1 * V;
-    float g2[KE], g2n[KE];
-    jrow_load<KE>(gb, V, lane, w.mg2[b * maxU1], g2);
-    for (int u = 0; u <= U; ++u) {
-      const float mg2 = w.mg2[b * maxU1 + u];
-      const float* grow = gb + (size_t)u * V;
-      if (u < U) jrow_load<KE>(grow + V, V, lane, w.mg2[b * maxU1 + u + 1], g2n);
-      const float gb2 = __builtin_fmaf(grow[blank], kLog2e, -mg2);
-      int lab = 0;
-      float gl2 = 0.f;
-      if (u < U) {
-        lab = labels[(size_t)b * (maxU1 - 1) + u];
-        if (lab < 0 || lab >= V) {
-          if (lane == 0) atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
-          lab = 0;
-        }
-        gl2 = __builtin_fmaf(grow[lab], kLog2e, -mg2);
+  utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
+  float4 rc = make_float4(kNegF, kNegF, 0.f, 0.f);
+  if (t < T && u <= U) {
+    const float* fr = f + (size_t)b * jg.fstride + (size_t)t * jg.V;
+    const float* gr = g + ((size_t)b * jg.maxU1 + u) * jg.V;
+    const float mf2 = w.mf2[b * jg.maxT + t], mg2 = w.mg2[b * jg.maxU1 + u];
+    rc.x = __builtin_fmaf(fr[jg.blank], kLog2e, -mf2) + __builtin_fmaf(gr[jg.blank], kLog2e, -mg2);
+    if (u < U) {
+      int lab = labels[(size_t)b * (jg.maxU1 - 1) + u];
+      if (lab < 0 || lab >= jg.V) {
+        atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
+        lab = 0;
       }
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        if (tt < nt) {
-          // sum_v 2^(f2+g2): every term <= 1 because the row maxima were subtracted
-          float s = 0.f;
-#pragma unroll
-          for (int k = 0; k < KE; ++k) s += fast_exp2(f2[tt][k] + g2[k]);
-          s = group_sum<64>(s);
-          float ls = fast_log2(s);
-          if (!(s > 1e-30f)) {
-            // the maxima of f and g sit at different v and every product underflowed: redo with the exact maximum
-            float m = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < KE; ++k) m = fmaxf(m, f2[tt][k] + g2[k]);
-            m = group_max<64>(m);
-            float s2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < KE; ++k) s2 += fast_exp2(f2[tt][k] + g2[k] - m);
-            s2 = group_sum<64>(s2);
-            ls = m + fast_log2(s2);
-          }
-          if (lane == 0) {
-            const float m2 = w.mf2[b * jg.maxT + t0 + tt];
-            const float fl2 = (u < U) ? __builtin_fmaf(frow[tt][lab], kLog2e, -m2) : 0.f;
-            my[tt * maxU1 + u] = make_float4(fb2[tt] + gb2 - ls, (u < U) ? fl2 + gl2 - ls : kNegF, ls, 0.f);
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < KE; ++k) g2[k] = g2n[k];
+      rc.y = __builtin_fmaf(fr[lab], kLog2e, -mf2) + __builtin_fmaf(gr[lab], kLog2e, -mg2);
     }
   }
-  // records of the tile's frames (log 0 where there is no cell), one contiguous burst per wave
+  w.rec[((size_t)b * (jg.maxT + 2) + 1 + t) * jg.maxU1 + u] = rc;
+  const float4 neg = make_float4(kNegF, kNegF, 0.f, 0.f);
+  if (t == 0) w.rec[((size_t)b * (jg.maxT + 2)) * jg.maxU1 + u] = neg;
+  if (t == jg.maxT - 1) w.rec[((size_t)b * (jg.maxT + 2) + 1 + jg.maxT) * jg.maxU1 + u] = neg;
+}
+
+template <int KE, int TT>
+__global__ __launch_bounds__(256) void k_joint_lse(const float* __restrict__ f, const float* __restrict__ g,
+                                                   const int32_t* __restrict__ in_len,
+                                                   const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
+  extern __shared__ float jls[];  // [4 waves][TT][maxU1] log2 of the cell sums
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ntile = (jg.maxT + TT - 1) / TT;  // frame tiles per utterance
+  const int blocks_per_b = (ntile + 3) / 4;
+  const int b = blockIdx.x / blocks_per_b;
+  const int tile = (blockIdx.x - b * blocks_per_b) * 4 + wv;
+  if (tile >= ntile) return;
+  const int t0 = tile * TT;
+  const int V = jg.V, maxU1 = jg.maxU1;
+  int T, U;
+  utt_dims(in_len, lab_len, b, jg.maxT, maxU1, T, U);
+  const int nt = min(TT, max(T - t0, 0));  // frames of this tile that hold cells
+  if (nt <= 0) return;                      // their records already say "log 0"
+  float* my = jls + (size_t)wv * TT * maxU1;
+
+  float f2[TT][KE];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int t = min(t0 + tt, jg.maxT - 1);
+    jrow_load<KE>(f + (size_t)b * jg.fstride + (size_t)t * V, V, lane, w.mf2[b * jg.maxT + t], f2[tt]);
+  }
+  const float* gb = g + (size_t)b * maxU1 * V;
+  const float* mg = w.mg2 + b * maxU1;
+  float g2[KE], g2n[KE];
+  jrow_load<KE>(gb, V, lane, mg[0], g2);
+  for (int u = 0; u <= U; ++u) {
+    // the next row of g is in flight while this one is used (row U+1 may not exist: clamp)
+    const int un = min(u + 1, maxU1 - 1);
+    jrow_load<KE>(gb + (size_t)un * V, V, lane, mg[un], g2n);
+    float s[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      // sum_v 2^(f2+g2): every term <= 1 because the row maxima were subtracted
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < KE; ++k) acc += fast_exp2(f2[tt][k] + g2[k]);
+      s[tt] = acc;
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) s[tt] = group_sum<64>(s[tt]);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      float ls = fast_log2(s[tt]);
+      if (!(s[tt] > 1e-30f)) {
+        // the maxima of f and g sit at different v and every product underflowed: redo with the exact maximum
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KE; ++k) m = fmaxf(m, f2[tt][k] + g2[k]);
+        m = group_max<64>(m);
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < KE; ++k) s2 += fast_exp2(f2[tt][k] + g2[k] - m);
+        ls = m + fast_log2(group_sum<64>(s2));
+      }
+      if (lane == 0) my[tt * maxU1 + u] = ls;
+    }
+#pragma unroll
+    for (int k = 0; k < KE; ++k) g2[k] = g2n[k];
+  }
+  // finish the records of the tile's cells: {x - ls, y - ls, ls} (coalesced read-modify-write per frame)
   float4* frame0 = w.rec + ((size_t)b * (jg.maxT + 2) + 1) * maxU1;
-  const int nfr = min(TT, jg.maxT - t0);
-  float4* out = frame0 + (size_t)t0 * maxU1;
-  for (int i = lane; i < nfr * maxU1; i += 64) out[i] = my[i];
-  if (t0 == 0)
-    for (int i = lane; i < maxU1; i += 64) (frame0 - maxU1)[i] = neg;
-  if (t0 + TT >= jg.maxT)
-    for (int i = lane; i < maxU1; i += 64) (frame0 + (size_t)jg.maxT * maxU1)[i] = neg;
+  for (int tt = 0; tt < nt; ++tt) {
+    float4* row = frame0 + (size_t)(t0 + tt) * maxU1;
+    for (int u = lane; u <= U; u += 64) {
+      float4 rc = row[u];
+      const float ls = my[tt * maxU1 + u];
+      rc.x -= ls;
+      rc.y = (u < U) ? rc.y - ls : kNegF;
+      rc.z = ls;
+      row[u] = rc;
+    }
+  }
 }
 
 // one thread per (b, t, u): {c, s*pb, s*pl, label}; c = log2 gamma - log2 s_cell, -inf when the cell is pruned
@@ -1308,21 +1328,25 @@ __global__ __launch_bounds__(256) void k_joint_grad_f(const float* __restrict__ 
       jrow_load<KE>(f + (size_t)b * jg.fstride + (size_t)t * V, V, lane, w.mf2[b * jg.maxT + t], f2[tt]);
     }
     const float* gb = g + (size_t)b * maxU1 * V;
-    const float4* cfb = w.coef + ((size_t)b * jg.maxT + t0) * maxU1;
+    const float* mg = w.mg2 + b * maxU1;
+    // coefficient rows of the tile's frames; frames beyond T_b re-read the last valid one and are masked below
+    const float4* cfrow[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) cfrow[tt] = w.coef + ((size_t)b * jg.maxT + min(t0 + tt, T - 1)) * maxU1;
+    float g2[KE], g2n[KE];
+    float4 cf[TT], cfn[TT];
+    jrow_load<KE>(gb, V, lane, mg[0], g2);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) cf[tt] = cfrow[tt][0];
     for (int u = 0; u <= U; ++u) {
-      float4 cf[TT];
-      bool any = false;
+      // next column's row of g and coefficients are in flight while this column is used
+      const int un = min(u + 1, maxU1 - 1);
+      jrow_load<KE>(gb + (size_t)un * V, V, lane, mg[un], g2n);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) cfn[tt] = cfrow[tt][un];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
-        cf[tt] = (tt < nt) ? cfb[(size_t)tt * maxU1 + u] : make_float4(-INFINITY, 0.f, 0.f, 0.f);
-        any |= cf[tt].x > -INFINITY;
-      }
-      if (!any) continue;  // uniform: coefficients are the same in every lane
-      float g2[KE];
-      jrow_load<KE>(gb + (size_t)u * V, V, lane, w.mg2[b * maxU1 + u], g2);
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        if (cf[tt].x > -INFINITY) {
+        if (tt < nt && cf[tt].x > -INFINITY) {  // uniform: the coefficients are the same in every lane
           const int lab = __float_as_int(cf[tt].w);
           const float c = cf[tt].x, plv = cf[tt].z;
           sumb[tt] += cf[tt].y;
@@ -1333,6 +1357,10 @@ __global__ __launch_bounds__(256) void k_joint_grad_f(const float* __restrict__ 
           }
         }
       }
+#pragma unroll
+      for (int k = 0; k < KE; ++k) g2[k] = g2n[k];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) cf[tt] = cfn[tt];
     }
   }
   // frames at or beyond T_b get zeros
@@ -1378,27 +1406,28 @@ __global__ __launch_bounds__(256) void k_joint_grad_g(const float* __restrict__ 
   }
   if (nu > 0) {
     float g2[UU][KE];
+    int ucol[UU];
 #pragma unroll
     for (int uu = 0; uu < UU; ++uu) {
-      const int u = min(u0 + uu, maxU1 - 1);
-      jrow_load<KE>(g + ((size_t)b * maxU1 + u) * V, V, lane, w.mg2[b * maxU1 + u], g2[uu]);
+      ucol[uu] = min(u0 + uu, U);  // columns beyond U_b re-read the last valid one and are masked below
+      jrow_load<KE>(g + ((size_t)b * maxU1 + ucol[uu]) * V, V, lane, w.mg2[b * maxU1 + ucol[uu]], g2[uu]);
     }
     const float* fb = f + (size_t)b * jg.fstride;
-    const float4* cfb = w.coef + (size_t)b * jg.maxT * maxU1 + u0;
+    const float* mf = w.mf2 + b * jg.maxT;
+    const float4* cfb = w.coef + (size_t)b * jg.maxT * maxU1;
+    float f2[KE], f2n[KE];
+    float4 cf[UU], cfn[UU];
+    jrow_load<KE>(fb, V, lane, mf[0], f2);
+#pragma unroll
+    for (int uu = 0; uu < UU; ++uu) cf[uu] = cfb[ucol[uu]];
     for (int t = 0; t < T; ++t) {
-      float4 cf[UU];
-      bool any = false;
+      const int tn = min(t + 1, T - 1);
+      jrow_load<KE>(fb + (size_t)tn * V, V, lane, mf[tn], f2n);
+#pragma unroll
+      for (int uu = 0; uu < UU; ++uu) cfn[uu] = cfb[(size_t)tn * maxU1 + ucol[uu]];
 #pragma unroll
       for (int uu = 0; uu < UU; ++uu) {
-        cf[uu] = (uu < nu) ? cfb[(size_t)t * maxU1 + uu] : make_float4(-INFINITY, 0.f, 0.f, 0.f);
-        any |= cf[uu].x > -INFINITY;
-      }
-      if (!any) continue;
-      float f2[KE];
-      jrow_load<KE>(fb + (size_t)t * V, V, lane, w.mf2[b * jg.maxT + t], f2);
-#pragma unroll
-      for (int uu = 0; uu < UU; ++uu) {
-        if (cf[uu].x > -INFINITY) {
+        if (uu < nu && cf[uu].x > -INFINITY) {
           const float c = cf[uu].x;
           sumb[uu] += cf[uu].y;
           suml[uu] += cf[uu].z;
@@ -1407,6 +1436,10 @@ __global__ __launch_bounds__(256) void k_joint_grad_g(const float* __restrict__ 
           for (int k = 0; k < KE; ++k) acc[uu][k] += sc * fast_exp2(f2[k] + g2[uu][k] + c);
         }
       }
+#pragma unroll
+      for (int k = 0; k < KE; ++k) f2[k] = f2n[k];
+#pragma unroll
+      for (int uu = 0; uu < UU; ++uu) cf[uu] = cfn[uu];
     }
   }
 #pragma unroll
@@ -1714,9 +1747,11 @@ int launch_joint_forward(const JointCall& c, float* costs, hipStream_t st) {
   k_init<<<1, 64, 0, st>>>(c.w, 0);
   const int rows = jg.B * (jg.maxT + jg.maxU1);
   k_joint_prep<<<(rows + 3) / 4, 256, 0, st>>>(c.f, c.g, jg, c.w);
+  const long long ncell = (long long)jg.B * jg.maxT * jg.maxU1;
+  k_joint_gather<<<(unsigned)((ncell + 255) / 256), 256, 0, st>>>(c.f, c.g, c.labels, c.in_len, c.lab_len, jg, c.w);
 #define JGRID_T(TT) dim3((unsigned)(jg.B * ((((jg.maxT + (TT)-1) / (TT)) + 3) / 4)))
-#define JLDS_T(TT) (sizeof(float4) * 4 * (size_t)(TT) * jg.maxU1)
-  RNNT_JOINT_DISPATCH(k_joint_lse, ke, JGRID_T, JLDS_T, 4, 2, 1, c.f, c.g, c.labels, c.in_len, c.lab_len, jg, c.w);
+#define JLDS_T(TT) (sizeof(float) * 4 * (size_t)(TT) * jg.maxU1)
+  RNNT_JOINT_DISPATCH(k_joint_lse, ke, JGRID_T, JLDS_T, 4, 2, 1, c.f, c.g, c.in_len, c.lab_len, jg, c.w);
   Call sc;  // the lattice sweep is the one of the materialised path
   sc.in_len = c.in_len; sc.lab_len = c.lab_len; sc.B = jg.B; sc.maxT = jg.maxT; sc.maxU1 = jg.maxU1;
   sc.costs = costs; sc.w = c.w;
