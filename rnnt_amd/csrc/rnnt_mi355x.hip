@@ -1751,7 +1751,7 @@ int launch_joint_forward(const JointCall& c, float* costs, hipStream_t st) {
   k_joint_gather<<<(unsigned)((ncell + 255) / 256), 256, 0, st>>>(c.f, c.g, c.labels, c.in_len, c.lab_len, jg, c.w);
 #define JGRID_T(TT) dim3((unsigned)(jg.B * ((((jg.maxT + (TT)-1) / (TT)) + 3) / 4)))
 #define JLDS_T(TT) (sizeof(float) * 4 * (size_t)(TT) * jg.maxU1)
-  RNNT_JOINT_DISPATCH(k_joint_lse, ke, JGRID_T, JLDS_T, 4, 2, 1, c.f, c.g, c.in_len, c.lab_len, jg, c.w);
+  RNNT_JOINT_DISPATCH(k_joint_lse, ke, JGRID_T, JLDS_T, 2, 1, 1, c.f, c.g, c.in_len, c.lab_len, jg, c.w);
   Call sc;  // the lattice sweep is the one of the materialised path
   sc.in_len = c.in_len; sc.lab_len = c.lab_len; sc.B = jg.B; sc.maxT = jg.maxT; sc.maxU1 = jg.maxU1;
   sc.costs = costs; sc.w = c.w;
