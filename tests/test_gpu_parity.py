@@ -256,3 +256,22 @@ def test_batch_strided_entry_points(V, blank):
     # a stride smaller than one utterance is rejected
     assert L.rnnt_mi355x_forward_strided(p(view), T * (U + 1) * V - 1, p(run.lab), p(run.il), p(run.ll), B, T, U + 1,
                                          V, blank, p(run.costs), p(run.ws), run.stream) == _lib.INVALID_VALUE
+
+
+def test_random_shapes_fuzz():
+    """40 seeded random problems (shape, vocabulary, blank position, ragged lengths, logit scale)
+    through rnnt_mi355x_loss_grad against the float64 oracle."""
+    rng = np.random.default_rng(20261111)
+    for case in range(40):
+        B = int(rng.integers(1, 6))
+        T = int(rng.integers(1, 40))
+        U = int(rng.integers(0, 30)) if case % 7 else int(rng.integers(60, 140))
+        V = int(rng.choice([2, 3, 7, 16, 31, 40, 62, 64, 65, 100, 128, 257, 300, 512, 777, 1024, 1500]))
+        blank = int(rng.integers(0, V))
+        scale = float(rng.choice([0.3, 1.0, 4.0, 12.0]))
+        x, lab, il, ll = make_batch(B, T, U, V, blank, seed=1000 + case, ragged=bool(case % 3), scale=scale)
+        gs = rng.uniform(0.2, 2.0, B).astype(np.float32) if case % 2 else None
+        try:
+            _check(x, lab, il, ll, blank, gs)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: B={B} T={T} U={U} V={V} blank={blank} scale={scale}: {e}")
