@@ -22,6 +22,13 @@ def test_known_answer():
         np.testing.assert_allclose(g, np.array(K[key + "_grad"]), atol=1e-6)
 
 
+def test_known_answer_batch():
+    x, lab, il, ll, blank, costs, grad = orc.known_answer_batch()
+    c, g = cpu_port.loss_grad(x.astype(np.float32), lab, il, ll, blank)
+    np.testing.assert_allclose(c, costs, rtol=COST_RTOL)
+    np.testing.assert_allclose(g, grad, atol=2e-6)
+
+
 def test_golden_fixtures(golden_dir):
     for f in sorted(glob.glob(os.path.join(golden_dir, "*.npz"))):
         if f.endswith("known_answer.npz"):

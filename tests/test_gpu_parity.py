@@ -53,6 +53,16 @@ def test_known_answer_vector():
         np.testing.assert_allclose(run.x.cpu().numpy(), np.array(K[key + "_grad"]), atol=2e-6)
 
 
+def test_known_answer_batch_vector():
+    """Published costs and gradient of the public B=2, T=4, U=2, V=3 vector."""
+    x, lab, il, ll, blank, costs, grad = orc.known_answer_batch()
+    run = HipRun(x.astype(np.float32), lab, il, ll, blank)
+    assert run.loss_grad() == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(run.costs.cpu().numpy(), costs, rtol=COST_RTOL)
+    np.testing.assert_allclose(run.x.cpu().numpy(), grad, atol=2e-6)
+
+
 def test_golden_fixtures(golden_dir):
     files = [f for f in sorted(glob.glob(os.path.join(golden_dir, "*.npz"))) if not f.endswith("known_answer.npz")]
     assert len(files) >= 8

@@ -34,6 +34,17 @@ def test_known_answer_rederived_independently(blank):
     np.testing.assert_allclose(ng, np.array(K[key + "_grad"]), atol=5e-8)
 
 
+def test_known_answer_batch_vector():
+    """Second public vector (B=2, T=4, U=2, V=3): published costs and gradient,
+    six decimals, computed upstream in float32."""
+    x, lab, il, ll, blank, costs, grad = orc.known_answer_batch()
+    c, g = orc.rnnt_loss_and_grad(x, lab, il, ll, blank)
+    np.testing.assert_allclose(c, costs, rtol=2e-7)
+    np.testing.assert_allclose(g, grad, atol=1e-6)
+    for b in range(2):  # and re-derived by enumerating every alignment
+        assert abs(orc.brute_force_cost(x[b], lab[b], 4, 2, blank) - costs[b]) < 1e-6
+
+
 @pytest.mark.parametrize("T,U,V,blank", [(1, 0, 3, 0), (1, 3, 4, 2), (4, 0, 3, 1), (3, 3, 5, 4), (4, 2, 6, 0), (2, 4, 3, 1)])
 def test_brute_force_paths(T, U, V, blank):
     rng = np.random.default_rng(T * 100 + U * 10 + V)
