@@ -167,7 +167,19 @@ def main():
         for r in ring:
             r.copy_(master)
 
+    def d2d_copy_rate():
+        """Device-to-device copy bandwidth of this box (read + write bytes per
+        second), the secondary denominator next to the spec peak."""
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ring[0].copy_(master)
+        a.record(stream)
+        ring[0].copy_(master)
+        b.record(stream)
+        b.synchronize()
+        return 2 * nbytes / (a.elapsed_time(b) * 1e-3) / 1e9
+
     ev_pairs = []
+    ev_steps = []  # (begin, end) of every timed step on the launch stream
 
     def new_event():
         e = torch.cuda.Event(enable_timing=True)
@@ -175,15 +187,18 @@ def main():
         return e
 
     def step(buf, timed):
-        e0 = e1 = None
+        e0 = e1 = s0 = None
         if timed:
             e0, e1 = new_event(), new_event()
+            s0 = new_event()
         rc = L.rnnt_mi355x_loss_grad_events(_p(buf), _p(labels), _p(il), _p(ll), *meta, _p(grad_scale), _p(costs),
                                             _p(ws), sp, ctypes.c_void_p(e0.cuda_event) if timed else None,
                                             ctypes.c_void_p(e1.cuda_event) if timed else None)
         if timed:
             ev_pairs.append((e0, e1))
         rc |= L.rnnt_mi355x_reduce_scalars(_p(costs), B, _p(ws), _p(scal), sp)
+        if timed:
+            ev_steps.append((s0, new_event()))
         if rc != 0:
             raise RuntimeError(f"rnnt_mi355x call failed: status {rc}")
         if world > 1:
@@ -246,6 +261,8 @@ def main():
     value = total_cells * args.steps / elapsed
     bpc = bytes_per_cell(V)
     grad_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs]))
+    step_ms = np.array([a.elapsed_time(b) for a, b in ev_steps])
+    d2d = d2d_copy_rate()
     achieved = cells * bpc / (grad_ms * 1e-3) / 1e9
 
     traffic = None
@@ -279,6 +296,9 @@ def main():
             "parallelism": f"utterance-sharded dp{world}, one 16-byte all-reduce per step" if world > 1 else "single GPU",
         },
         "step_hbm_frac_of_peak": value / world * bpc / (HBM_PEAK_GBS * 1e9),
+        "step_ms_device": {"median": float(np.median(step_ms)), "min": float(step_ms.min()), "max": float(step_ms.max())},
+        "d2d_copy_GBs": d2d,
+        "step_frac_of_d2d_copy": value / world * bpc / (d2d * 1e9),
         "roofline": {
             "bound": "hbm", "kernel": "k_grad (in-place gradient pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

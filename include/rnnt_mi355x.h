@@ -127,7 +127,7 @@ int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, con
  * util.py:107-109).  Needs the larger workspace of
  * rnnt_mi355x_joint_workspace_bytes; V <= 4096.  rnnt_mi355x_reduce_scalars
  * after a joint backward returns the cost sum and 0 for the norm. */
-int rnnt_mi355x_joint_workspace_bytes(int B, int maxT, int maxU1, size_t* out_bytes);
+int rnnt_mi355x_joint_workspace_bytes(int B, int maxT, int maxU1, int V, size_t* out_bytes);
 int rnnt_mi355x_joint_forward(const float* f, size_t f_batch_stride, const float* g, const int32_t* labels,
                               const int32_t* in_len, const int32_t* lab_len, int B, int maxT, int maxU1, int V,
                               int blank, float* costs, void* workspace, void* hip_stream);

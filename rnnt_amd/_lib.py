@@ -35,7 +35,7 @@ _SIGNATURES = {
     "rnnt_mi355x_backward_inplace": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp]),
     "rnnt_mi355x_loss_grad": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp]),
     "rnnt_mi355x_loss_grad_events": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp, _vp, _vp]),
-    "rnnt_mi355x_joint_workspace_bytes": (ctypes.c_int, [_i, _i, _i, ctypes.POINTER(_sz)]),
+    "rnnt_mi355x_joint_workspace_bytes": (ctypes.c_int, [_i, _i, _i, _i, ctypes.POINTER(_sz)]),
     "rnnt_mi355x_joint_forward": (ctypes.c_int, [_vp, _sz] + [_vp] * 4 + _META + [_vp, _vp, _vp]),
     "rnnt_mi355x_joint_backward": (ctypes.c_int, [_vp, _sz] + [_vp] * 4 + _META + [_vp, _vp, _sz, _vp, _vp, _vp]),
     "rnnt_mi355x_reduce_scalars": (ctypes.c_int, [_vp, _i, _vp, _vp, _vp]),
@@ -82,9 +82,9 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"{what}: {status_string(rc)} (status {rc})")
 
 
-def joint_workspace_bytes(B: int, maxT: int, maxU1: int) -> int:
+def joint_workspace_bytes(B: int, maxT: int, maxU1: int, V: int) -> int:
     out = _sz(0)
-    check(lib().rnnt_mi355x_joint_workspace_bytes(B, maxT, maxU1, ctypes.byref(out)), "rnnt_mi355x_joint_workspace_bytes")
+    check(lib().rnnt_mi355x_joint_workspace_bytes(B, maxT, maxU1, V, ctypes.byref(out)), "rnnt_mi355x_joint_workspace_bytes")
     return int(out.value)
 
 

@@ -46,7 +46,8 @@ struct Header {
   int32_t flags;          // OR of RNNT_MI355X_FLAG_*
   int32_t n_partial;      // entries of `partial` the last k_grad wrote
   uint64_t partial_off;   // byte offset of `partial` from the workspace base
-  int32_t pad[60];
+  int32_t n_fallback;     // fused joint: lattice cells whose linear-domain sum underflowed (handled by the exp path)
+  int32_t pad[59];
 };
 static_assert(sizeof(Header) == 256, "header is one 256-byte block");
 
@@ -63,7 +64,14 @@ struct Ws {
   // fused additive joint only:
   float* mf2;      // [B][maxT]  max_v f(b,t,v) * log2(e)
   float* mg2;      // [B][maxU1] max_v g(b,u,v) * log2(e)
-  float4* coef;    // [B][maxT][maxU1] {c, pb, pl, label as int bits} per cell (c = -inf: no gradient)
+  float4* coef;    // [B][maxT][maxU1] {c, pb, pl, label code} per cell (c = -inf: no gradient)
+  // Operands of the three contractions, zero-padded, each stored in tiles of 32 rows x 8 columns
+  // ([row tile][column chunk][32][8], see tiled_off) so that every wavefront load is a run of whole cache lines:
+  float* Fp;       // [B] rows t < Tp,  columns v < Vp:  2^(f*log2e - mf2)
+  float* Gp;       // [B] rows u < U1p, columns v < Vp:  2^(g*log2e - mg2)
+  float* Ctu;      // [B] rows t < Tp,  columns u < U1p: C = s_b * gamma / (cell sum); 0 where nothing flows through the products
+  float* Cut;      // [B] rows u < U1p, columns t < Tp:  the same numbers transposed
+  int Vp, U1p, Tp; // padded extents: maxT and maxU1 rounded up to 32, V to 32 / 64 / a multiple of 128
   size_t partial_off;
   int D;    // diagonals = maxT + maxU1 - 1
   int U1s;  // row stride = 64 * sweep_cols_per_lane(maxU1)
@@ -77,7 +85,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int sweep_cols_per_lane(int maxU1) { return maxU1 <= 64 ? 1 : maxU1 <= 128 ? 2 : maxU1 <= 256 ? 4 : 8; }
 
 // Lays the workspace out; returns total bytes.  base may be null (size query).
-size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = false) {
+size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = false, int V = 0) {
   const int D = maxT + maxU1 - 1;
   const int U1s = 64 * sweep_cols_per_lane(maxU1);
   const size_t plane = (size_t)B * D * U1s;
@@ -97,6 +105,12 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
   const size_t o_mf2 = joint ? take(sizeof(float) * (size_t)B * maxT) : 0;
   const size_t o_mg2 = joint ? take(sizeof(float) * (size_t)B * maxU1) : 0;
   const size_t o_coef = joint ? take(sizeof(float4) * (size_t)B * maxT * maxU1) : 0;
+  const int Vp = V <= 32 ? 32 : V <= 64 ? 64 : (int)align_up((size_t)V, 128);
+  const int U1p = (int)align_up((size_t)maxU1, 32), Tp = (int)align_up((size_t)maxT, 32);
+  const size_t o_Fp = joint ? take(sizeof(float) * (size_t)B * Tp * Vp) : 0;
+  const size_t o_Gp = joint ? take(sizeof(float) * (size_t)B * U1p * Vp) : 0;
+  const size_t o_Ctu = joint ? take(sizeof(float) * (size_t)B * Tp * U1p) : 0;
+  const size_t o_Cut = joint ? take(sizeof(float) * (size_t)B * Tp * U1p) : 0;
   if (w) {
     w->hdr = reinterpret_cast<Header*>(p + o_hdr);
     w->ll = reinterpret_cast<double*>(p + o_ll);
@@ -107,6 +121,11 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
     w->mf2 = joint ? reinterpret_cast<float*>(p + o_mf2) : nullptr;
     w->mg2 = joint ? reinterpret_cast<float*>(p + o_mg2) : nullptr;
     w->coef = joint ? reinterpret_cast<float4*>(p + o_coef) : nullptr;
+    w->Fp = joint ? reinterpret_cast<float*>(p + o_Fp) : nullptr;
+    w->Gp = joint ? reinterpret_cast<float*>(p + o_Gp) : nullptr;
+    w->Ctu = joint ? reinterpret_cast<float*>(p + o_Ctu) : nullptr;
+    w->Cut = joint ? reinterpret_cast<float*>(p + o_Cut) : nullptr;
+    w->Vp = Vp; w->U1p = U1p; w->Tp = Tp;
     w->partial_off = o_partial;
     w->D = D;
     w->U1s = U1s;
@@ -1108,24 +1127,44 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
 // ---------------------------------------------------------------------------
 // Fused additive joint (reference Util.rnnt_lambda_func, rnnt/base/util.py:
 // 107-109: acts = log_softmax(y_trans[B,T,1,V] + y_pred[B,1,U+1,V])).  The
-// [B,T,U+1,V] tensor is never formed: with f = y_trans, g = y_pred,
-//   lse(t,u)   = mf(t) + mg(u) + log sum_v exp(f(t,v)-mf(t) + g(u,v)-mg(u))
-//   d f(t,v)   = sum_u dx(t,u,v),   d g(u,v) = sum_t dx(t,u,v)
-// so HBM traffic falls from O(T*U*V) to O((T+U)*V) and the work becomes
-// exp-throughput bound.  Lanes own the vocabulary entries v = lane + 64k; a
-// wavefront keeps a few rows of one operand in registers and streams the rows
-// of the other one past them (they are L2-resident).
-//   k_joint_prep   row maxima mf2, mg2 (base-2)
-//   k_joint_lse    records {lpb, lpl, log2 s} of every cell  (then k_sweep as usual)
-//   k_joint_coef   {c, pb, pl, label} of every cell from alpha, beta, ll
-//   k_joint_grad_f d f: a wave owns TT frames, loops over u
-//   k_joint_grad_g d g: a wave owns UU columns, loops over t   (recomputes the exponentials: no atomics)
+// [B,T,U+1,V] tensor is never formed.  With f = y_trans, g = y_pred and
+//   F(t,v) = exp(f(t,v) - max_v f(t,.)),   G(u,v) = exp(g(u,v) - max_v g(u,.))
+// the sum over the vocabulary of every cell is a matrix product,
+//   S(t,u) = sum_v F(t,v) G(u,v),      lse(t,u) = mf(t) + mg(u) + log S(t,u),
+// and so are the two gradients: with C(t,u) = s_b * gamma(t,u) / S(t,u)
+//   d f(t,v) = F(t,v) * sum_u C(t,u) G(u,v)  - (blank / label terms)
+//   d g(u,v) = G(u,v) * sum_t C(t,u) F(t,v)  - (blank / label terms)
+// Three batched float32 contractions on the matrix cores
+// (v_mfma_f32_32x32x2_f32, operands straight from L2-resident global memory)
+// replace T*U*V exponentials.  Cells whose S underflows (maxima of f and g at
+// different v, far apart) are recomputed with the exact maximum, flagged, and
+// their gradient goes through the exponent-domain kernels further down.
+//   k_joint_prep    mf2, mg2 (base-2 row maxima), F, G
+//   k_joint_gather  blank / label parts of every cell's record
+//   k_joint_lse_mm  S -> records {lpb, lpl, log2 S}          (then k_sweep as usual)
+//   k_joint_coef    {c, pb, pl, label code} and C of every cell from alpha, beta, ll
+//   k_joint_df_mm, k_joint_dg_mm   the two gradient contractions
+//   k_joint_corr_f, k_joint_corr_g the blank / label terms
+//   k_joint_fix_f, k_joint_fix_g   exponent-domain contributions of flagged cells (exit at once when there are none)
 // ---------------------------------------------------------------------------
 struct JointGeom {
   int B, maxT, maxU1, V, blank;
   size_t fstride;  // elements between utterances of f (>= maxT*V): lets f be a crop along T of a larger tensor
   size_t dfstride; // same for d f
 };
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+constexpr float kJointMinSum = 5.421010862427522e-20f;  // 2^-64: below this the linear-domain sum is not trusted
+constexpr int kJointFlagBit = 1 << 20;                  // label code = (label + 1) | flag; labels < 4096
+
+__device__ __forceinline__ f4v ld4(const float* p) { return *reinterpret_cast<const f4v*>(p); }
+
+// Offset of element (row, col) of a matrix stored in tiles of 32 rows x 8 columns, `chunks` = padded columns / 8.
+// A wavefront whose lanes take rows r0..r0+31 and 4 consecutive columns each (lanes 0-31 columns c..c+3, lanes
+// 32-63 columns c+4..c+7) reads 1 KiB of consecutive addresses; 8 consecutive rows of 8 columns are 2 lines.
+__device__ __forceinline__ size_t tiled_off(int row, int col, int chunks) {
+  return ((((size_t)(row >> 5) * chunks) + (col >> 3)) << 8) + ((row & 31) << 3) + (col & 7);
+}
 
 // out[k] = row[lane+64k]*log2(e) - m2, or -inf past the end of the row
 template <int KE>
@@ -1138,31 +1177,45 @@ __device__ __forceinline__ void jrow_load(const float* row, int V, int lane, flo
   }
 }
 
+// One wavefront per 4 consecutive (padded) rows of f or g: their base-2 maxima, then their part of F or G in the
+// tiled layout (4 rows x 8 columns = one 128-byte line per store group).  Padding rows and columns become zeros.
 __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f, const float* __restrict__ g,
                                                     JointGeom jg, Ws w) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int nf = jg.B * jg.maxT, ng = jg.B * jg.maxU1;
-  if (row >= nf + ng) return;
-  const float* p;
-  if (row < nf) {
-    const int b = row / jg.maxT, t = row - b * jg.maxT;
-    p = f + (size_t)b * jg.fstride + (size_t)t * jg.V;
-  } else {
-    p = g + (size_t)(row - nf) * jg.V;
+  const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ngf = jg.B * (w.Tp / 4), ngg = jg.B * (w.U1p / 4);
+  if (grp >= ngf + ngg) return;
+  const bool isf = grp < ngf;
+  const int R = isf ? w.Tp : w.U1p, real = isf ? jg.maxT : jg.maxU1;
+  const int r0 = (isf ? grp : grp - ngf) * 4;
+  const int b = r0 / R, rr0 = r0 - b * R;
+  const int V = jg.V, chunks = w.Vp >> 3;
+  const float* src[4];
+  float m[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = min(rr0 + q, real - 1);
+    src[q] = isf ? f + (size_t)b * jg.fstride + (size_t)row * V : g + ((size_t)b * jg.maxU1 + row) * V;
+    float mx = -INFINITY;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, src[q][v]);
+    m[q] = group_max<64>(mx) * kLog2e;
+    if (lane == 0 && rr0 + q < real) (isf ? w.mf2 + b * jg.maxT : w.mg2 + b * jg.maxU1)[rr0 + q] = m[q];
   }
-  float m = -INFINITY;
-  for (int v = lane; v < jg.V; v += 64) m = fmaxf(m, p[v]);
-  m = group_max<64>(m);
-  if (lane == 0) {
-    if (row < nf) w.mf2[row] = m * kLog2e;
-    else w.mg2[row - nf] = m * kLog2e;
+  const int q = (lane & 31) >> 3, e = lane & 7;
+  const float* my = q == 0 ? src[0] : q == 1 ? src[1] : q == 2 ? src[2] : src[3];
+  const float mq = q == 0 ? m[0] : q == 1 ? m[1] : q == 2 ? m[2] : m[3];
+  const bool row_ok = rr0 + q < real;
+  float* out = (isf ? w.Fp : w.Gp) + (size_t)b * R * w.Vp + tiled_off(rr0 + q, 0, chunks) + e;
+  for (int c = lane >> 5; c < chunks; c += 2) {
+    const int v = c * 8 + e;
+    const float x = my[min(v, V - 1)];
+    out[(size_t)c << 8] = (row_ok && v < V) ? fast_exp2(__builtin_fmaf(x, kLog2e, -mq)) : 0.f;
   }
 }
 
 // One thread per (b, t, u): the part of the cell's record that does not need the sum over V,
 //   {f2(t,blank) + g2(u,blank), f2(t,y_{u+1}) + g2(u,y_{u+1}), 0, 0}   (f2 = f*log2e - mf2, g2 likewise)
-// so that k_joint_lse has no data-dependent address in its loop.  Entries that are no lattice cell get "log 0".
+// Entries that are no lattice cell get "log 0".
 __global__ __launch_bounds__(256) void k_joint_gather(const float* __restrict__ f, const float* __restrict__ g,
                                                       const int32_t* __restrict__ labels,
                                                       const int32_t* __restrict__ in_len,
@@ -1196,13 +1249,357 @@ __global__ __launch_bounds__(256) void k_joint_gather(const float* __restrict__ 
   if (t == jg.maxT - 1) w.rec[((size_t)b * (jg.maxT + 2) + 1 + jg.maxT) * jg.maxU1 + u] = neg;
 }
 
-template <int KE, int TT>
-__global__ __launch_bounds__(256) void k_joint_lse(const float* __restrict__ f, const float* __restrict__ g,
-                                                   const int32_t* __restrict__ in_len,
-                                                   const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
-  extern __shared__ float jls[];  // [4 waves][TT][maxU1] log2 of the cell sums
+// log2 sum_v 2^(f2(t,v) + g2(u,v)) with the exact maximum taken out first; all 64 lanes cooperate.
+__device__ __noinline__ float joint_exact_ls(const float* __restrict__ f, const float* __restrict__ g,
+                                             const JointGeom& jg, const Ws& w, int b, int t, int u, int lane) {
+  const float* fr = f + (size_t)b * jg.fstride + (size_t)t * jg.V;
+  const float* gr = g + ((size_t)b * jg.maxU1 + u) * jg.V;
+  const float mf2 = w.mf2[b * jg.maxT + t], mg2 = w.mg2[b * jg.maxU1 + u];
+  float m = -INFINITY;
+  for (int v = lane; v < jg.V; v += 64)
+    m = fmaxf(m, __builtin_fmaf(fr[v], kLog2e, -mf2) + __builtin_fmaf(gr[v], kLog2e, -mg2));
+  m = group_max<64>(m);
+  float s = 0.f;
+  for (int v = lane; v < jg.V; v += 64)
+    s += fast_exp2(__builtin_fmaf(fr[v], kLog2e, -mf2) + __builtin_fmaf(gr[v], kLog2e, -mg2) - m);
+  return m + fast_log2(group_sum<64>(s));
+}
+
+// Tile coordinates of one wavefront of a batched contraction: M tiles of 32 rows vary fastest (the four waves
+// of a block then share their N strip), then N strips, then utterances.
+struct MmTile {
+  int b, m0, n0;
+  bool ok;
+};
+__device__ __forceinline__ MmTile mm_tile(int B, int m_tiles, int n_strips, int n_strip_cols) {
+  MmTile mt;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int per_b = m_tiles * n_strips;
+  mt.ok = wid < B * per_b;
+  mt.b = wid / per_b;
+  const int r = wid - mt.b * per_b;
+  const int in = r / m_tiles;
+  mt.m0 = (r - in * m_tiles) * 32;
+  mt.n0 = in * n_strip_cols;
+  return mt;
+}
+
+// Row of C/D register r of a 32x32 MFMA tile held by this lane (the column is lane % 32).
+__device__ __forceinline__ int mm_row(int r, int lane) { return 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); }
+
+// S(t,u) = sum_v F(t,v) G(u,v) for a 32 x 32*NT tile per wavefront, then the cell records.  Both operands are
+// K-contiguous: a lane loads 4 consecutive v of its row per step (lanes 0-31 take v = k..k+3, lanes 32-63
+// v = k+4..k+7; the order of the sum over v is free) and feeds them to 4 MFMAs.  The operands of the next
+// step are in flight during this step's MFMAs.
+template <int NT>
+__global__ __launch_bounds__(256) void k_joint_lse_mm(const float* __restrict__ f, const float* __restrict__ g,
+                                                      const int32_t* __restrict__ in_len,
+                                                      const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
+  const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5;
+  const MmTile mt = mm_tile(jg.B, w.Tp / 32, (w.U1p + 32 * NT - 1) / (32 * NT), 32 * NT);
+  if (!mt.ok) return;
+  const int b = mt.b, t0 = mt.m0, u0 = mt.n0;
+  int T, U;
+  utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
+  if (t0 >= T || u0 > U) return;  // no lattice cell in this tile: its records already say "log 0"
+  const int Vp = w.Vp, chunks = Vp >> 3;
+  const float* ap = w.Fp + (size_t)b * w.Tp * Vp + tiled_off(t0 + l32, 4 * h, chunks);
+  const float* bp[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)  // a strip may reach past the padded rows of G: such tiles re-read the last one
+    bp[j] = w.Gp + (size_t)b * w.U1p * Vp + tiled_off(min(u0 + 32 * j, w.U1p - 32) + l32, 4 * h, chunks);
+  f16v acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  f4v a = ld4(ap), bb[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bb[j] = ld4(bp[j]);
+  for (int c = 0; c < chunks; ++c) {
+    const size_t on = (size_t)min(c + 1, chunks - 1) << 8;
+    const f4v an = ld4(ap + on);
+    f4v bn[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bn[j] = ld4(bp[j] + on);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j][i], acc[j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    a = an;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bb[j] = bn[j];
+  }
+  float4* frame0 = w.rec + ((size_t)b * (jg.maxT + 2) + 1) * jg.maxU1;
+  int n_bad = 0;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = t0 + mm_row(r, lane), u = u0 + 32 * j + l32;
+      const bool valid = t < T && u <= U;
+      const float S = acc[j][r];
+      float ls = fast_log2(S);
+      const bool bad = valid && !(S >= kJointMinSum);
+      unsigned long long m = __ballot(bad);
+      while (m) {  // rare: redo the cell with the exact maximum
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float e = joint_exact_ls(f, g, jg, w, b, __shfl(t, src), __shfl(u, src), lane);
+        if (lane == src) ls = e;
+      }
+      n_bad += bad ? 1 : 0;
+      if (valid) {
+        float4* cell = frame0 + (size_t)t * jg.maxU1 + u;
+        float4 rc = *cell;
+        rc.x -= ls;
+        rc.y = (u < U) ? rc.y - ls : kNegF;
+        rc.z = ls;
+        rc.w = bad ? 1.f : 0.f;
+        *cell = rc;
+      }
+    }
+  }
+  if (n_bad) atomicAdd(&w.hdr->n_fallback, n_bad);
+}
+
+// One thread per (b, t < Tp, u < U1p): {c, s*pb, s*pl, label code} of the cell (c = log2 gamma - log2 S, -inf
+// when the cell is pruned) and C = s * 2^c for the contractions (0 where pruned, flagged, or outside the lattice).
+__global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ labels,
+                                                    const int32_t* __restrict__ in_len,
+                                                    const int32_t* __restrict__ lab_len,
+                                                    const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int per_b = w.Tp * w.U1p;
+  if (i >= (long long)jg.B * per_b) return;
+  const int b = (int)(i / per_b);
+  const int rem = (int)(i - (long long)b * per_b);
+  const int t = rem / w.U1p, u = rem - t * w.U1p;
+  float cm = 0.f;
+  if (t < jg.maxT && u < jg.maxU1) {
+    int T, U;
+    utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
+    const CellRaw raw = cell_load(w, labels, b, t, u, T, U, jg.maxT, jg.maxU1, jg.V, true);
+    float4 cf = cell_coef(raw);
+    const float sc = grad_scale ? grad_scale[b] : 1.f;
+    cf.y *= sc;
+    cf.z *= sc;
+    const bool live = cf.x > -INFINITY;
+    const bool flagged = live && raw.rc.w != 0.f;
+    cf.w = __int_as_float((raw.lab + 1) | (flagged ? kJointFlagBit : 0));
+    if (live && !flagged) cm = sc * fast_exp2(cf.x);
+    w.coef[((size_t)b * jg.maxT + t) * jg.maxU1 + u] = cf;
+  }
+  w.Ctu[(size_t)b * per_b + tiled_off(t, u, w.U1p >> 3)] = cm;
+  w.Cut[(size_t)b * per_b + tiled_off(u, t, w.Tp >> 3)] = cm;
+}
+
+// NT consecutive floats
+template <int NT>
+struct FVec;
+template <>
+struct FVec<1> { typedef float type; };
+template <>
+struct FVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <>
+struct FVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <int NT>
+__device__ __forceinline__ float fvec_get(const typename FVec<NT>::type& v, int j) { return v[j]; }
+template <>
+__device__ __forceinline__ float fvec_get<1>(const float& v, int) { return v; }
+
+// out(m, n) = E(m, n) * sum_k A(m, k) Bm(k, n) for one wavefront tile of 32 rows x 32*NT columns, where
+//   A   is K-contiguous tiled (`a_base` + row tile m0, `a_chunks` = padded K / 8),
+//   Bm  is N-contiguous tiled with rows k (`b_base`, chunks = Vp / 8): G for d f, F for d g,
+//   E   is the tiled matrix multiplied in element-wise at the end (`e_base`, rows m): F for d f, G for d g.
+// Lane l of MFMA tile j owns column n0 + NT*(l%32) + j, so that one load of NT consecutive floats feeds all NT
+// tiles and the results leave as NT consecutive floats.
+template <int NT>
+__device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, int a_chunks, int kmax,
+                                              const float* __restrict__ b_base, const float* __restrict__ e_base,
+                                              int Vp, int m0, int n0, int m_real, int V, float* __restrict__ out,
+                                              bool vec_ok, int lane) {
+  typedef typename FVec<NT>::type vecn;
+  const int l32 = lane & 31, h = lane >> 5, chunks = Vp >> 3;
+  const int col = n0 + NT * l32;
+  const float* ap = a_base + tiled_off(m0 + l32, 4 * h, a_chunks);
+  const float* bp = b_base + tiled_off(4 * h, col, chunks);  // + 8 floats per row, + 256*chunks per 32 rows
+  f16v acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  auto b_off = [&](int k0, int i) { return ((size_t)(k0 >> 5) * chunks << 8) + (((k0 & 31) + i) << 3); };
+  if (kmax > 0) {
+    f4v a = ld4(ap);
+    vecn bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const vecn*>(bp + b_off(0, i));
+    for (int k0 = 0; k0 < kmax; k0 += 8) {
+      const int kn = min(k0 + 8, kmax - 8);
+      const f4v an = ld4(ap + ((size_t)(kn >> 3) << 8));
+      vecn bn[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bn[i] = *reinterpret_cast<const vecn*>(bp + b_off(kn, i));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], fvec_get<NT>(bv[i], j), acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a = an;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bv[i] = bn[i];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + mm_row(r, lane);
+    if (m >= m_real) continue;
+    const vecn e = *reinterpret_cast<const vecn*>(e_base + tiled_off(m, col, chunks));
+    float* o = out + (size_t)m * V + col;
+    if (vec_ok && col + NT <= V) {
+      vecn res;
+      if constexpr (NT == 1) res = e * acc[0][r];
+      else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) res[j] = e[j] * acc[j][r];
+      }
+      *reinterpret_cast<vecn*>(o) = res;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        if (col + j < V) o[j] = fvec_get<NT>(e, j) * acc[j][r];
+    }
+  }
+}
+
+// d f(t,v) = F(t,v) * sum_u C(t,u) G(u,v): M = frames, N = vocabulary, K = label positions.
+template <int NT>
+__global__ __launch_bounds__(256) void k_joint_df_mm(float* __restrict__ df, const int32_t* __restrict__ in_len,
+                                                     const int32_t* __restrict__ lab_len, JointGeom jg, Ws w,
+                                                     bool vec_ok) {
+  const MmTile mt = mm_tile(jg.B, w.Tp / 32, w.Vp / (32 * NT), 32 * NT);
+  if (!mt.ok) return;
+  int T, U;
+  utt_dims(in_len, lab_len, mt.b, jg.maxT, jg.maxU1, T, U);
+  const int kmax = (mt.m0 < T) ? (U + 8) & ~7 : 0;  // C is zero beyond column U_b and in frames >= T_b
+  const size_t cb = (size_t)mt.b * w.Tp * w.U1p;
+  joint_grad_mm<NT>(w.Ctu + cb, w.U1p >> 3, kmax, w.Gp + (size_t)mt.b * w.U1p * w.Vp,
+                    w.Fp + (size_t)mt.b * w.Tp * w.Vp, w.Vp, mt.m0, mt.n0, jg.maxT, jg.V,
+                    df + (size_t)mt.b * jg.dfstride, vec_ok, threadIdx.x & 63);
+}
+
+// d g(u,v) = G(u,v) * sum_t C(t,u) F(t,v): M = label positions, N = vocabulary, K = frames.
+template <int NT>
+__global__ __launch_bounds__(256) void k_joint_dg_mm(float* __restrict__ dg, const int32_t* __restrict__ in_len,
+                                                     const int32_t* __restrict__ lab_len, JointGeom jg, Ws w,
+                                                     bool vec_ok) {
+  const MmTile mt = mm_tile(jg.B, w.U1p / 32, w.Vp / (32 * NT), 32 * NT);
+  if (!mt.ok) return;
+  int T, U;
+  utt_dims(in_len, lab_len, mt.b, jg.maxT, jg.maxU1, T, U);
+  const int kmax = (mt.m0 <= U) ? (T + 7) & ~7 : 0;  // C is zero in frames >= T_b and columns > U_b
+  const size_t cb = (size_t)mt.b * w.Tp * w.U1p;
+  joint_grad_mm<NT>(w.Cut + cb, w.Tp >> 3, kmax, w.Fp + (size_t)mt.b * w.Tp * w.Vp,
+                    w.Gp + (size_t)mt.b * w.U1p * w.Vp, w.Vp, mt.m0, mt.n0, jg.maxU1, jg.V,
+                    dg + (size_t)mt.b * jg.maxU1 * jg.V, vec_ok, threadIdx.x & 63);
+}
+
+// Blank and label terms of d f: one wavefront per frame.  d f(t, y) -= sum over the positions u whose next
+// label is y of s*pl(t,u), and d f(t, blank) -= sum_u s*pb(t,u).  Positions with the same label are summed by
+// the lane of the first of them in a fixed order, so the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void k_joint_corr_f(float* __restrict__ df, const int32_t* __restrict__ in_len,
+                                                      const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
+  extern __shared__ int jcs[];  // per wave: target index [maxU1+1], value [maxU1+1]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int ntile = (jg.maxT + TT - 1) / TT;  // frame tiles per utterance
+  const int n = jg.maxU1 + 1;
+  int* tgt = jcs + (size_t)wv * 2 * n;
+  float* val = reinterpret_cast<float*>(tgt + n);
+  const int row = blockIdx.x * 4 + wv;
+  const bool in_rows = row < jg.B * jg.maxT;
+  const int b = in_rows ? row / jg.maxT : 0, t = in_rows ? row - b * jg.maxT : 0;
+  int T, U;
+  utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
+  const bool active = in_rows && t < T;
+  if (active) {
+    const float4* cfrow = w.coef + ((size_t)b * jg.maxT + t) * jg.maxU1;
+    float sumb = 0.f;
+    for (int u = lane; u <= U; u += 64) {
+      const float4 cf = cfrow[u];
+      sumb += cf.y;
+      tgt[u] = (__float_as_int(cf.w) & (kJointFlagBit - 1)) - 1;  // -1: no label term
+      val[u] = cf.z;
+    }
+    sumb = group_sum<64>(sumb);
+    if (lane == 0) {
+      tgt[U + 1] = jg.blank;
+      val[U + 1] = sumb;
+    }
+  }
+  __syncthreads();
+  if (active) {
+    float* out = df + (size_t)b * jg.dfstride + (size_t)t * jg.V;
+    for (int u = lane; u <= U + 1; u += 64) {
+      const int my = tgt[u];
+      bool leader = my >= 0;
+      for (int k = 0; k < u; ++k) leader = leader && tgt[k] != my;
+      if (leader) {
+        float s = 0.f;
+        for (int k = u; k <= U + 1; ++k) s += (tgt[k] == my) ? val[k] : 0.f;
+        out[my] -= s;
+      }
+    }
+  }
+}
+
+// Blank and label terms of d g: 64 label positions per block, the frames split over the four waves.
+__global__ __launch_bounds__(256) void k_joint_corr_g(float* __restrict__ dg, const int32_t* __restrict__ labels,
+                                                      const int32_t* __restrict__ in_len,
+                                                      const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ublocks = (jg.maxU1 + 63) / 64;
+  const int b = blockIdx.x / ublocks;
+  const int u = (blockIdx.x - b * ublocks) * 64 + lane;
+  int T, U;
+  utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
+  float sb = 0.f, sl = 0.f;
+  if (u <= U) {
+    const float4* cfb = w.coef + (size_t)b * jg.maxT * jg.maxU1 + u;
+    for (int t = wv; t < T; t += 4) {
+      const float4 cf = cfb[(size_t)t * jg.maxU1];
+      sb += cf.y;
+      sl += cf.z;
+    }
+  }
+  red[0][wv][lane] = sb;
+  red[1][wv][lane] = sl;
+  __syncthreads();
+  if (wv == 0 && u <= U && T > 0) {
+    sb = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    sl = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    float* out = dg + ((size_t)b * jg.maxU1 + u) * jg.V;
+    out[jg.blank] -= sb;
+    if (u < U) {
+      const int l = labels[(size_t)b * (jg.maxU1 - 1) + u];
+      out[(l < 0 || l >= jg.V) ? 0 : l] -= sl;
+    }
+  }
+}
+
+// Exponent-domain contribution of the flagged cells to d f: a wave owns TT frames and loops over u.
+template <int KE, int TT>
+__global__ __launch_bounds__(256) void k_joint_fix_f(const float* __restrict__ f, const float* __restrict__ g,
+                                                     float* __restrict__ df, const int32_t* __restrict__ in_len,
+                                                     const int32_t* __restrict__ lab_len,
+                                                     const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
+  if (w.hdr->n_fallback == 0) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ntile = (jg.maxT + TT - 1) / TT;
   const int blocks_per_b = (ntile + 3) / 4;
   const int b = blockIdx.x / blocks_per_b;
   const int tile = (blockIdx.x - b * blocks_per_b) * 4 + wv;
@@ -1211,10 +1608,15 @@ __global__ __launch_bounds__(256) void k_joint_lse(const float* __restrict__ f, 
   const int V = jg.V, maxU1 = jg.maxU1;
   int T, U;
   utt_dims(in_len, lab_len, b, jg.maxT, maxU1, T, U);
-  const int nt = min(TT, max(T - t0, 0));  // frames of this tile that hold cells
-  if (nt <= 0) return;                      // their records already say "log 0"
-  float* my = jls + (size_t)wv * TT * maxU1;
-
+  const float sc = grad_scale ? grad_scale[b] : 1.f;
+  const int nt = min(TT, max(T - t0, 0));
+  if (nt <= 0) return;
+  float acc[TT][KE];
+  bool any = false;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int k = 0; k < KE; ++k) acc[tt][k] = 0.f;
   float f2[TT][KE];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
@@ -1223,166 +1625,39 @@ __global__ __launch_bounds__(256) void k_joint_lse(const float* __restrict__ f, 
   }
   const float* gb = g + (size_t)b * maxU1 * V;
   const float* mg = w.mg2 + b * maxU1;
-  float g2[KE], g2n[KE];
-  jrow_load<KE>(gb, V, lane, mg[0], g2);
   for (int u = 0; u <= U; ++u) {
-    // the next row of g is in flight while this one is used (row U+1 may not exist: clamp)
-    const int un = min(u + 1, maxU1 - 1);
-    jrow_load<KE>(gb + (size_t)un * V, V, lane, mg[un], g2n);
-    float s[TT];
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
-      // sum_v 2^(f2+g2): every term <= 1 because the row maxima were subtracted
-      float acc = 0.f;
+      if (tt >= nt) continue;
+      const float4 cf = w.coef[((size_t)b * jg.maxT + t0 + tt) * maxU1 + u];  // uniform over the wave
+      if (!(__float_as_int(cf.w) & kJointFlagBit)) continue;
+      any = true;
+      float g2[KE];
+      jrow_load<KE>(gb + (size_t)u * V, V, lane, mg[u], g2);
 #pragma unroll
-      for (int k = 0; k < KE; ++k) acc += fast_exp2(f2[tt][k] + g2[k]);
-      s[tt] = acc;
-    }
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) s[tt] = group_sum<64>(s[tt]);
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-      float ls = fast_log2(s[tt]);
-      if (!(s[tt] > 1e-30f)) {
-        // the maxima of f and g sit at different v and every product underflowed: redo with the exact maximum
-        float m = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < KE; ++k) m = fmaxf(m, f2[tt][k] + g2[k]);
-        m = group_max<64>(m);
-        float s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < KE; ++k) s2 += fast_exp2(f2[tt][k] + g2[k] - m);
-        ls = m + fast_log2(group_sum<64>(s2));
-      }
-      if (lane == 0) my[tt * maxU1 + u] = ls;
-    }
-#pragma unroll
-    for (int k = 0; k < KE; ++k) g2[k] = g2n[k];
-  }
-  // finish the records of the tile's cells: {x - ls, y - ls, ls} (coalesced read-modify-write per frame)
-  float4* frame0 = w.rec + ((size_t)b * (jg.maxT + 2) + 1) * maxU1;
-  for (int tt = 0; tt < nt; ++tt) {
-    float4* row = frame0 + (size_t)(t0 + tt) * maxU1;
-    for (int u = lane; u <= U; u += 64) {
-      float4 rc = row[u];
-      const float ls = my[tt * maxU1 + u];
-      rc.x -= ls;
-      rc.y = (u < U) ? rc.y - ls : kNegF;
-      rc.z = ls;
-      row[u] = rc;
+      for (int k = 0; k < KE; ++k) acc[tt][k] += sc * fast_exp2(f2[tt][k] + g2[k] + cf.x);
     }
   }
-}
-
-// one thread per (b, t, u): {c, s*pb, s*pl, label}; c = log2 gamma - log2 s_cell, -inf when the cell is pruned
-__global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ labels,
-                                                    const int32_t* __restrict__ in_len,
-                                                    const int32_t* __restrict__ lab_len,
-                                                    const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long n = (long long)jg.B * jg.maxT * jg.maxU1;
-  if (i >= n) return;
-  const int per_b = jg.maxT * jg.maxU1;
-  const int b = (int)(i / per_b);
-  const int rem = (int)(i - (long long)b * per_b);
-  const int t = rem / jg.maxU1, u = rem - t * jg.maxU1;
-  int T, U;
-  utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
-  float4 cf = cell_coef(cell_load(w, labels, b, t, u, T, U, jg.maxT, jg.maxU1, jg.V, true));
-  const float sc = grad_scale ? grad_scale[b] : 1.f;
-  cf.y *= sc;
-  cf.z *= sc;
-  w.coef[i] = cf;
-}
-
-template <int KE, int TT>
-__global__ __launch_bounds__(256) void k_joint_grad_f(const float* __restrict__ f, const float* __restrict__ g,
-                                                      float* __restrict__ df, const int32_t* __restrict__ in_len,
-                                                      const int32_t* __restrict__ lab_len,
-                                                      const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int ntile = (jg.maxT + TT - 1) / TT;
-  const int blocks_per_b = (ntile + 3) / 4;
-  const int b = blockIdx.x / blocks_per_b;
-  const int tile = (blockIdx.x - b * blocks_per_b) * 4 + wv;
-  if (tile >= ntile) return;
-  const int t0 = tile * TT;
-  const int V = jg.V, maxU1 = jg.maxU1, blank = jg.blank;
-  int T, U;
-  utt_dims(in_len, lab_len, b, jg.maxT, maxU1, T, U);
-  const float sc = grad_scale ? grad_scale[b] : 1.f;
-  const int nt = min(TT, max(T - t0, 0));
-  float acc[TT][KE];
-  float sumb[TT];
+  if (!any) return;
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
-    sumb[tt] = 0.f;
+    if (tt >= nt) continue;
+    float* out = df + (size_t)b * jg.dfstride + (size_t)(t0 + tt) * V;
 #pragma unroll
-    for (int k = 0; k < KE; ++k) acc[tt][k] = 0.f;
-  }
-  if (nt > 0) {
-    float f2[TT][KE];
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-      const int t = min(t0 + tt, jg.maxT - 1);
-      jrow_load<KE>(f + (size_t)b * jg.fstride + (size_t)t * V, V, lane, w.mf2[b * jg.maxT + t], f2[tt]);
-    }
-    const float* gb = g + (size_t)b * maxU1 * V;
-    const float* mg = w.mg2 + b * maxU1;
-    // coefficient rows of the tile's frames; frames beyond T_b re-read the last valid one and are masked below
-    const float4* cfrow[TT];
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) cfrow[tt] = w.coef + ((size_t)b * jg.maxT + min(t0 + tt, T - 1)) * maxU1;
-    float g2[KE], g2n[KE];
-    float4 cf[TT], cfn[TT];
-    jrow_load<KE>(gb, V, lane, mg[0], g2);
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) cf[tt] = cfrow[tt][0];
-    for (int u = 0; u <= U; ++u) {
-      // next column's row of g and coefficients are in flight while this column is used
-      const int un = min(u + 1, maxU1 - 1);
-      jrow_load<KE>(gb + (size_t)un * V, V, lane, mg[un], g2n);
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) cfn[tt] = cfrow[tt][un];
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        if (tt < nt && cf[tt].x > -INFINITY) {  // uniform: the coefficients are the same in every lane
-          const int lab = __float_as_int(cf[tt].w);
-          const float c = cf[tt].x, plv = cf[tt].z;
-          sumb[tt] += cf[tt].y;
-#pragma unroll
-          for (int k = 0; k < KE; ++k) {
-            const float e = sc * fast_exp2(f2[tt][k] + g2[k] + c);
-            acc[tt][k] += e - ((lane + 64 * k == lab) ? plv : 0.f);
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < KE; ++k) g2[k] = g2n[k];
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) cf[tt] = cfn[tt];
-    }
-  }
-  // frames at or beyond T_b get zeros
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    const int t = t0 + tt;
-    if (t < jg.maxT) {
-      float* out = df + (size_t)b * jg.dfstride + (size_t)t * V;
-#pragma unroll
-      for (int k = 0; k < KE; ++k) {
-        const int v = lane + 64 * k;
-        if (v < V) out[v] = acc[tt][k] - ((v == blank) ? sumb[tt] : 0.f);
-      }
+    for (int k = 0; k < KE; ++k) {
+      const int v = lane + 64 * k;
+      if (v < V) out[v] += acc[tt][k];
     }
   }
 }
 
+// Same for d g: a wave owns UU label positions and loops over t.
 template <int KE, int UU>
-__global__ __launch_bounds__(256) void k_joint_grad_g(const float* __restrict__ f, const float* __restrict__ g,
-                                                      float* __restrict__ dg, const int32_t* __restrict__ in_len,
-                                                      const int32_t* __restrict__ lab_len,
-                                                      const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
+__global__ __launch_bounds__(256) void k_joint_fix_g(const float* __restrict__ f, const float* __restrict__ g,
+                                                     float* __restrict__ dg, const int32_t* __restrict__ in_len,
+                                                     const int32_t* __restrict__ lab_len,
+                                                     const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
+  if (w.hdr->n_fallback == 0) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ntile = (jg.maxU1 + UU - 1) / UU;
   const int blocks_per_b = (ntile + 3) / 4;
@@ -1390,68 +1665,48 @@ __global__ __launch_bounds__(256) void k_joint_grad_g(const float* __restrict__ 
   const int tile = (blockIdx.x - b * blocks_per_b) * 4 + wv;
   if (tile >= ntile) return;
   const int u0 = tile * UU;
-  const int V = jg.V, maxU1 = jg.maxU1, blank = jg.blank;
+  const int V = jg.V, maxU1 = jg.maxU1;
   int T, U;
   utt_dims(in_len, lab_len, b, jg.maxT, maxU1, T, U);
   const float sc = grad_scale ? grad_scale[b] : 1.f;
-  const int nu = (T > 0) ? min(UU, max(U + 1 - u0, 0)) : 0;  // columns of this tile that hold cells
+  const int nu = (T > 0) ? min(UU, max(U + 1 - u0, 0)) : 0;
+  if (nu <= 0) return;
   float acc[UU][KE];
-  float sumb[UU], suml[UU];
-  int lab[UU];
+  bool any = false;
 #pragma unroll
-  for (int uu = 0; uu < UU; ++uu) {
-    sumb[uu] = 0.f; suml[uu] = 0.f; lab[uu] = -1;
+  for (int uu = 0; uu < UU; ++uu)
 #pragma unroll
     for (int k = 0; k < KE; ++k) acc[uu][k] = 0.f;
-  }
-  if (nu > 0) {
-    float g2[UU][KE];
-    int ucol[UU];
-#pragma unroll
-    for (int uu = 0; uu < UU; ++uu) {
-      ucol[uu] = min(u0 + uu, U);  // columns beyond U_b re-read the last valid one and are masked below
-      jrow_load<KE>(g + ((size_t)b * maxU1 + ucol[uu]) * V, V, lane, w.mg2[b * maxU1 + ucol[uu]], g2[uu]);
-    }
-    const float* fb = f + (size_t)b * jg.fstride;
-    const float* mf = w.mf2 + b * jg.maxT;
-    const float4* cfb = w.coef + (size_t)b * jg.maxT * maxU1;
-    float f2[KE], f2n[KE];
-    float4 cf[UU], cfn[UU];
-    jrow_load<KE>(fb, V, lane, mf[0], f2);
-#pragma unroll
-    for (int uu = 0; uu < UU; ++uu) cf[uu] = cfb[ucol[uu]];
-    for (int t = 0; t < T; ++t) {
-      const int tn = min(t + 1, T - 1);
-      jrow_load<KE>(fb + (size_t)tn * V, V, lane, mf[tn], f2n);
-#pragma unroll
-      for (int uu = 0; uu < UU; ++uu) cfn[uu] = cfb[(size_t)tn * maxU1 + ucol[uu]];
-#pragma unroll
-      for (int uu = 0; uu < UU; ++uu) {
-        if (uu < nu && cf[uu].x > -INFINITY) {
-          const float c = cf[uu].x;
-          sumb[uu] += cf[uu].y;
-          suml[uu] += cf[uu].z;
-          lab[uu] = __float_as_int(cf[uu].w);
-#pragma unroll
-          for (int k = 0; k < KE; ++k) acc[uu][k] += sc * fast_exp2(f2[k] + g2[uu][k] + c);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < KE; ++k) f2[k] = f2n[k];
-#pragma unroll
-      for (int uu = 0; uu < UU; ++uu) cf[uu] = cfn[uu];
-    }
-  }
+  float g2[UU][KE];
 #pragma unroll
   for (int uu = 0; uu < UU; ++uu) {
-    const int u = u0 + uu;
-    if (u < maxU1) {
-      float* out = dg + ((size_t)b * maxU1 + u) * V;
+    const int u = min(u0 + uu, U);
+    jrow_load<KE>(g + ((size_t)b * maxU1 + u) * V, V, lane, w.mg2[b * maxU1 + u], g2[uu]);
+  }
+  const float* fb = f + (size_t)b * jg.fstride;
+  const float* mf = w.mf2 + b * jg.maxT;
+  for (int t = 0; t < T; ++t) {
 #pragma unroll
-      for (int k = 0; k < KE; ++k) {
-        const int v = lane + 64 * k;
-        if (v < V) out[v] = acc[uu][k] - ((v == blank) ? sumb[uu] : 0.f) - ((v == lab[uu]) ? suml[uu] : 0.f);
-      }
+    for (int uu = 0; uu < UU; ++uu) {
+      if (uu >= nu) continue;
+      const float4 cf = w.coef[((size_t)b * jg.maxT + t) * maxU1 + u0 + uu];  // uniform over the wave
+      if (!(__float_as_int(cf.w) & kJointFlagBit)) continue;
+      any = true;
+      float f2[KE];
+      jrow_load<KE>(fb + (size_t)t * V, V, lane, mf[t], f2);
+#pragma unroll
+      for (int k = 0; k < KE; ++k) acc[uu][k] += sc * fast_exp2(f2[k] + g2[uu][k] + cf.x);
+    }
+  }
+  if (!any) return;
+#pragma unroll
+  for (int uu = 0; uu < UU; ++uu) {
+    if (uu >= nu) continue;
+    float* out = dg + ((size_t)b * maxU1 + u0 + uu) * V;
+#pragma unroll
+    for (int k = 0; k < KE; ++k) {
+      const int v = lane + 64 * k;
+      if (v < V) out[v] += acc[uu][k];
     }
   }
 }
@@ -1459,6 +1714,7 @@ __global__ __launch_bounds__(256) void k_joint_grad_g(const float* __restrict__ 
 __global__ __launch_bounds__(64) void k_init(Ws w, int n_partial) {
   if (threadIdx.x == 0) {
     w.hdr->flags = 0;
+    w.hdr->n_fallback = 0;
     w.hdr->n_partial = n_partial;
     w.hdr->partial_off = w.partial_off;
   }
@@ -1724,52 +1980,79 @@ int make_joint_call(JointCall* c, const float* f, size_t fstride, const float* g
   c->jg.B = B; c->jg.maxT = maxT; c->jg.maxU1 = maxU1; c->jg.V = V; c->jg.blank = blank;
   c->jg.fstride = fstride ? fstride : dense;
   c->jg.dfstride = dfstride ? dfstride : dense;
-  ws_layout(workspace, B, maxT, maxU1, &c->w, true);
+  ws_layout(workspace, B, maxT, maxU1, &c->w, true, V);
   return RNNT_MI355X_OK;
 }
 
-#define RNNT_JOINT_DISPATCH(KERNEL, ke, GRID, LDS, T16, T32, T64, ...)                       \
-  do {                                                                                       \
-    switch (ke) {                                                                            \
-      case 1: KERNEL<1, 4><<<GRID(4), 256, LDS(4), st>>>(__VA_ARGS__); break;                \
-      case 2: KERNEL<2, 4><<<GRID(4), 256, LDS(4), st>>>(__VA_ARGS__); break;                \
-      case 4: KERNEL<4, 4><<<GRID(4), 256, LDS(4), st>>>(__VA_ARGS__); break;                \
-      case 8: KERNEL<8, 4><<<GRID(4), 256, LDS(4), st>>>(__VA_ARGS__); break;                \
-      case 16: KERNEL<16, T16><<<GRID(T16), 256, LDS(T16), st>>>(__VA_ARGS__); break;        \
-      case 32: KERNEL<32, T32><<<GRID(T32), 256, LDS(T32), st>>>(__VA_ARGS__); break;        \
-      default: KERNEL<64, T64><<<GRID(T64), 256, LDS(T64), st>>>(__VA_ARGS__); break;        \
-    }                                                                                        \
+#define RNNT_JOINT_DISPATCH(KERNEL, ke, GRID, T16, T32, T64, ...)                       \
+  do {                                                                                  \
+    switch (ke) {                                                                       \
+      case 1: KERNEL<1, 4><<<GRID(4), 256, 0, st>>>(__VA_ARGS__); break;                \
+      case 2: KERNEL<2, 4><<<GRID(4), 256, 0, st>>>(__VA_ARGS__); break;                \
+      case 4: KERNEL<4, 4><<<GRID(4), 256, 0, st>>>(__VA_ARGS__); break;                \
+      case 8: KERNEL<8, 4><<<GRID(4), 256, 0, st>>>(__VA_ARGS__); break;                \
+      case 16: KERNEL<16, T16><<<GRID(T16), 256, 0, st>>>(__VA_ARGS__); break;          \
+      case 32: KERNEL<32, T32><<<GRID(T32), 256, 0, st>>>(__VA_ARGS__); break;          \
+      default: KERNEL<64, T64><<<GRID(T64), 256, 0, st>>>(__VA_ARGS__); break;          \
+    }                                                                                   \
   } while (0)
+
+// blocks of four wavefronts for a batched contraction with m_tiles x n_strips wavefront tiles per utterance
+inline unsigned mm_blocks(int B, int m_tiles, int n_strips) {
+  return (unsigned)(((long long)B * m_tiles * n_strips + 3) / 4);
+}
 
 int launch_joint_forward(const JointCall& c, float* costs, hipStream_t st) {
   const JointGeom& jg = c.jg;
-  const int ke = joint_ke(jg.V);
-  k_init<<<1, 64, 0, st>>>(c.w, 0);
-  const int rows = jg.B * (jg.maxT + jg.maxU1);
-  k_joint_prep<<<(rows + 3) / 4, 256, 0, st>>>(c.f, c.g, jg, c.w);
+  const Ws& w = c.w;
+  k_init<<<1, 64, 0, st>>>(w, 0);
+  const int groups = jg.B * ((w.Tp + w.U1p) / 4);
+  k_joint_prep<<<(groups + 3) / 4, 256, 0, st>>>(c.f, c.g, jg, w);
   const long long ncell = (long long)jg.B * jg.maxT * jg.maxU1;
-  k_joint_gather<<<(unsigned)((ncell + 255) / 256), 256, 0, st>>>(c.f, c.g, c.labels, c.in_len, c.lab_len, jg, c.w);
-#define JGRID_T(TT) dim3((unsigned)(jg.B * ((((jg.maxT + (TT)-1) / (TT)) + 3) / 4)))
-#define JLDS_T(TT) (sizeof(float) * 4 * (size_t)(TT) * jg.maxU1)
-  RNNT_JOINT_DISPATCH(k_joint_lse, ke, JGRID_T, JLDS_T, 2, 1, 1, c.f, c.g, c.in_len, c.lab_len, jg, c.w);
+  k_joint_gather<<<(unsigned)((ncell + 255) / 256), 256, 0, st>>>(c.f, c.g, c.labels, c.in_len, c.lab_len, jg, w);
+  const int mt = w.Tp / 32;
+  if (w.U1p <= 32)
+    k_joint_lse_mm<1><<<mm_blocks(jg.B, mt, 1), 256, 0, st>>>(c.f, c.g, c.in_len, c.lab_len, jg, w);
+  else
+    k_joint_lse_mm<2><<<mm_blocks(jg.B, mt, (w.U1p + 63) / 64), 256, 0, st>>>(c.f, c.g, c.in_len, c.lab_len, jg, w);
   Call sc;  // the lattice sweep is the one of the materialised path
   sc.in_len = c.in_len; sc.lab_len = c.lab_len; sc.B = jg.B; sc.maxT = jg.maxT; sc.maxU1 = jg.maxU1;
-  sc.costs = costs; sc.w = c.w;
+  sc.costs = costs; sc.w = w;
   launch_sweep(sc, 0, jg.B, st);
   return launch_status();
 }
 
 int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df, float* dg, hipStream_t st) {
   const JointGeom& jg = c.jg;
+  const Ws& w = c.w;
   const int ke = joint_ke(jg.V);
-  const long long cells = (long long)jg.B * jg.maxT * jg.maxU1;
-  k_joint_coef<<<(unsigned)((cells + 255) / 256), 256, 0, st>>>(c.labels, c.in_len, c.lab_len, grad_scale, jg, c.w);
-#define JLDS_0(TT) 0
-  RNNT_JOINT_DISPATCH(k_joint_grad_f, ke, JGRID_T, JLDS_0, 2, 1, 1, c.f, c.g, df, c.in_len, c.lab_len, grad_scale, jg,
-                      c.w);
+  const long long padded = (long long)jg.B * w.Tp * w.U1p;
+  k_joint_coef<<<(unsigned)((padded + 255) / 256), 256, 0, st>>>(c.labels, c.in_len, c.lab_len, grad_scale, jg, w);
+  const int mt = w.Tp / 32, mu = w.U1p / 32;
+  const int nt = w.Vp <= 32 ? 1 : w.Vp <= 64 ? 2 : 4;
+  // results may leave as vectors of nt floats when every row of d f / d g starts on a multiple of nt floats
+  auto aligned = [&](const float* p, size_t stride) {
+    return jg.V % nt == 0 && stride % nt == 0 && reinterpret_cast<uintptr_t>(p) % (sizeof(float) * nt) == 0;
+  };
+  const bool vf = aligned(df, jg.dfstride), vg = aligned(dg, (size_t)nt);
+  const int ns = w.Vp / (32 * nt);
+  if (nt == 1) {
+    k_joint_df_mm<1><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
+    k_joint_dg_mm<1><<<mm_blocks(jg.B, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
+  } else if (nt == 2) {
+    k_joint_df_mm<2><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
+    k_joint_dg_mm<2><<<mm_blocks(jg.B, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
+  } else {
+    k_joint_df_mm<4><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
+    k_joint_dg_mm<4><<<mm_blocks(jg.B, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
+  }
+  const size_t corr_lds = sizeof(int) * 4 * 2 * (size_t)(jg.maxU1 + 1);
+  k_joint_corr_f<<<(jg.B * jg.maxT + 3) / 4, 256, corr_lds, st>>>(df, c.in_len, c.lab_len, jg, w);
+  k_joint_corr_g<<<jg.B * ((jg.maxU1 + 63) / 64), 256, 0, st>>>(dg, c.labels, c.in_len, c.lab_len, jg, w);
+#define JGRID_T(TT) dim3((unsigned)(jg.B * ((((jg.maxT + (TT)-1) / (TT)) + 3) / 4)))
 #define JGRID_U(UU) dim3((unsigned)(jg.B * ((((jg.maxU1 + (UU)-1) / (UU)) + 3) / 4)))
-  RNNT_JOINT_DISPATCH(k_joint_grad_g, ke, JGRID_U, JLDS_0, 2, 1, 1, c.f, c.g, dg, c.in_len, c.lab_len, grad_scale, jg,
-                      c.w);
+  RNNT_JOINT_DISPATCH(k_joint_fix_f, ke, JGRID_T, 2, 1, 1, c.f, c.g, df, c.in_len, c.lab_len, grad_scale, jg, w);
+  RNNT_JOINT_DISPATCH(k_joint_fix_g, ke, JGRID_U, 2, 1, 1, c.f, c.g, dg, c.in_len, c.lab_len, grad_scale, jg, w);
   return launch_status();
 }
 
@@ -1777,7 +2060,7 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
 
 extern "C" {
 
-int rnnt_mi355x_version(void) { return 100; }
+int rnnt_mi355x_version(void) { return 101; }
 
 const char* rnnt_mi355x_status_string(int status) {
   switch (status) {
@@ -1865,11 +2148,12 @@ int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, con
                           static_cast<hipEvent_t>(ev_grad_end));
 }
 
-int rnnt_mi355x_joint_workspace_bytes(int B, int maxT, int maxU1, size_t* out_bytes) {
+int rnnt_mi355x_joint_workspace_bytes(int B, int maxT, int maxU1, int V, size_t* out_bytes) {
   if (!out_bytes) return RNNT_MI355X_INVALID_VALUE;
-  const int rc = check_shape(B, maxT, maxU1, 1, 0);
+  const int rc = check_shape(B, maxT, maxU1, V, 0);
   if (rc != RNNT_MI355X_OK) return rc;
-  *out_bytes = ws_layout(nullptr, B, maxT, maxU1, nullptr, true);
+  if (V > 4096) return RNNT_MI355X_UNSUPPORTED_SIZE;
+  *out_bytes = ws_layout(nullptr, B, maxT, maxU1, nullptr, true, V);
   return RNNT_MI355X_OK;
 }
 

@@ -181,7 +181,7 @@ class _RNNTJointLossFn(torch.autograd.Function):
         fview = f_full[:, t_offset:]
         fstride = fview.stride(0) if B > 1 else T * V
         with torch.cuda.device(dev):
-            ws = torch.empty(_lib.joint_workspace_bytes(B, T, U1), dtype=torch.uint8, device=dev)
+            ws = torch.empty(_lib.joint_workspace_bytes(B, T, U1, V), dtype=torch.uint8, device=dev)
             costs = torch.empty(B, dtype=torch.float32, device=dev)
             rc = _lib.lib().rnnt_mi355x_joint_forward(_ptr(fview), fstride, _ptr(g), _ptr(labels), _ptr(il), _ptr(ll),
                                                       B, T, U1, V, blank, _ptr(costs), _ptr(ws), _stream_ptr(dev))

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_version_and_status_strings():
-    assert _lib.lib().rnnt_mi355x_version() == 100
+    assert _lib.lib().rnnt_mi355x_version() == 101
     assert _lib.status_string(0) == "ok"
     for rc in (1, 2, 3, 4, 99):
         assert _lib.status_string(rc)

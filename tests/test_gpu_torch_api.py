@@ -185,6 +185,8 @@ JOINT_SHAPES = [  # B, T, U, V, blank -> every elements-per-lane variant of the 
     (3, 9, 4, 40, 39), (2, 11, 5, 62, 39), (2, 8, 3, 100, 0), (2, 7, 4, 200, 199), (2, 9, 3, 512, 5),
     (2, 6, 4, 1000, 999), (2, 5, 2, 1024, 1023), (1, 4, 3, 2000, 7), (1, 3, 2, 4096, 4095), (2, 1, 3, 30, 2),
     (2, 6, 0, 30, 2), (1, 20, 130, 16, 15),
+    # several 32-row tiles / column strips of the contractions, ragged edges in every dimension
+    (2, 70, 40, 150, 149), (1, 45, 70, 33, 0), (2, 33, 64, 129, 64), (1, 100, 12, 300, 17),
 ]
 
 
@@ -231,6 +233,52 @@ def test_fused_joint_equals_materialised_path_and_handles_separated_maxima():
     np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
     assert np.abs(tf_.grad.cpu().numpy() - gj.sum(2)).max() < GRAD_ATOL
     assert np.abs(tg.grad.cpu().numpy() - gj.sum(1)).max() < GRAD_ATOL
+
+
+def test_fused_joint_with_some_cells_below_the_linear_domain_floor():
+    """Only part of the lattice has separated maxima, by a margin (60 nats = 2^-87)
+    that leaves the linear-domain sum representable but below the trusted floor:
+    flagged and unflagged cells then share rows of d f and d g."""
+    B, T, U, V, blank = 2, 40, 9, 70, 69
+    rng = np.random.default_rng(41)
+    f = rng.standard_normal((B, T, V)).astype(np.float32)
+    g = rng.standard_normal((B, U + 1, V)).astype(np.float32)
+    f[:, 5:23:2, 3] += 60.0
+    g[:, 2:7, 50] += 60.0
+    lab = rng.integers(0, V - 1, (B, U)).astype(np.int32)
+    il, ll = np.array([T, T - 7], np.int32), np.array([U, 6], np.int32)
+    joint = f[:, :, None, :] + g[:, None, :, :]
+    w = np.array([0.7, 1.3], np.float32)
+    co, gj = orc.rnnt_loss_and_grad(joint, lab, il, ll, blank, w)
+    tf_ = torch.from_numpy(f).to(DEV).requires_grad_(True)
+    tg = torch.from_numpy(g).to(DEV).requires_grad_(True)
+    costs = rnnt_amd.rnnt_joint_loss(tf_, tg, lab, il, ll, blank)
+    (costs * torch.from_numpy(w).to(DEV)).sum().backward()
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+    assert np.abs(tf_.grad.cpu().numpy() - gj.sum(2)).max() < GRAD_ATOL
+    assert np.abs(tg.grad.cpu().numpy() - gj.sum(1)).max() < GRAD_ATOL
+
+
+def test_fused_joint_is_deterministic_with_repeated_labels():
+    B, T, U, V, blank = 2, 37, 20, 12, 3   # 20 labels over 11 symbols: many repeats; blank mid-vocabulary
+    rng = np.random.default_rng(43)
+    f = rng.standard_normal((B, T, V)).astype(np.float32)
+    g = rng.standard_normal((B, U + 1, V)).astype(np.float32)
+    lab = rng.integers(0, V - 1, (B, U)).astype(np.int32)
+    lab[lab >= blank] += 1
+    il, ll = np.array([T, 30], np.int32), np.array([U, 13], np.int32)
+    joint = f[:, :, None, :] + g[:, None, :, :]
+    co, gj = orc.rnnt_loss_and_grad(joint, lab, il, ll, blank)
+    outs = []
+    for _ in range(3):
+        tf_ = torch.from_numpy(f).to(DEV).requires_grad_(True)
+        tg = torch.from_numpy(g).to(DEV).requires_grad_(True)
+        rnnt_amd.rnnt_joint_loss(tf_, tg, lab, il, ll, blank).sum().backward()
+        outs.append((tf_.grad.clone(), tg.grad.clone()))
+    assert np.abs(outs[0][0].cpu().numpy() - gj.sum(2)).max() < GRAD_ATOL
+    assert np.abs(outs[0][1].cpu().numpy() - gj.sum(1)).max() < GRAD_ATOL
+    for a, b in outs[1:]:
+        assert torch.equal(a, outs[0][0]) and torch.equal(b, outs[0][1])
 
 
 def test_lambda_func_fused_and_unfused_agree():

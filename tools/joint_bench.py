@@ -16,7 +16,7 @@ lab = torch.randint(0, V - 1, (B, U), device=dev, dtype=torch.int32)
 il = torch.full((B,), T, dtype=torch.int32, device=dev); ll = torch.full((B,), U, dtype=torch.int32, device=dev)
 gs = torch.full((B,), 1.0 / B, device=dev); costs = torch.empty(B, device=dev)
 df = torch.empty_like(f); dg = torch.empty_like(g)
-ws = torch.empty(_lib.joint_workspace_bytes(B, T, U1), dtype=torch.uint8, device=dev)
+ws = torch.empty(_lib.joint_workspace_bytes(B, T, U1, V), dtype=torch.uint8, device=dev)
 sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 meta = (B, T, U1, V, blank)
 def fused():
@@ -41,4 +41,4 @@ m1, m2 = materialised(); torch.cuda.synchronize()
 print("max |dcost|", (c1 - costs).abs().max().item(), "max |d df|", (d1 - m1).abs().max().item(), "max |d dg|", (d2 - m2).abs().max().item())
 tf, tm = timeit(fused), timeit(materialised)
 cells = B * T * U1
-print(f"config {a.config}: fused joint {tf:.3f} ms ({cells/tf/1e6:.0f} Mcells/s) | materialised add+loss_grad+reduce {tm:.3f} ms ({cells/tm/1e6:.0f} Mcells/s) | speed-up {tm/tf:.1f}x")
+print(f"config {a.config}: fused joint {tf:.3f} ms ({cells/tf/1e3:.0f} Mcells/s) | materialised add+loss_grad+reduce {tm:.3f} ms ({cells/tm/1e3:.0f} Mcells/s) | speed-up {tm/tf:.1f}x")
