@@ -1178,7 +1178,10 @@ __device__ __forceinline__ void jrow_load(const float* row, int V, int lane, flo
 }
 
 // One wavefront per 4 consecutive (padded) rows of f or g: their base-2 maxima, then their part of F or G in the
-// tiled layout (4 rows x 8 columns = one 128-byte line per store group).  Padding rows and columns become zeros.
+// tiled layout.  Lane = (row q of 4, column chunk cc of 8, half e4 of a chunk): one step reads 256 contiguous
+// bytes of each of the 4 rows and writes 8 whole 128-byte lines.  Padding rows and columns become zeros.
+// VEC4: rows start on 16-byte boundaries (V % 4 == 0, aligned bases), so the reads are float4.
+template <bool VEC4>
 __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f, const float* __restrict__ g,
                                                     JointGeom jg, Ws w) {
   const int lane = threadIdx.x & 63;
@@ -1190,26 +1193,40 @@ __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f,
   const int r0 = (isf ? grp : grp - ngf) * 4;
   const int b = r0 / R, rr0 = r0 - b * R;
   const int V = jg.V, chunks = w.Vp >> 3;
-  const float* src[4];
-  float m[4];
+  const int q = lane >> 4, cc = (lane >> 1) & 7, e4 = (lane & 1) * 4;
+  const int row = rr0 + q;
+  const bool row_ok = row < real;
+  const int rowc = min(row, real - 1);
+  const float* src = isf ? f + (size_t)b * jg.fstride + (size_t)rowc * V : g + ((size_t)b * jg.maxU1 + rowc) * V;
+  auto load4 = [&](int v, float (&x)[4]) {  // elements v..v+3 of the row, -inf past its end
+    if (VEC4) {
+      const f4v t = ld4(src + min(v, V - 4));
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = min(rr0 + q, real - 1);
-    src[q] = isf ? f + (size_t)b * jg.fstride + (size_t)row * V : g + ((size_t)b * jg.maxU1 + row) * V;
-    float mx = -INFINITY;
-    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, src[q][v]);
-    m[q] = group_max<64>(mx) * kLog2e;
-    if (lane == 0 && rr0 + q < real) (isf ? w.mf2 + b * jg.maxT : w.mg2 + b * jg.maxU1)[rr0 + q] = m[q];
+      for (int i = 0; i < 4; ++i) x[i] = v < V ? t[i] : -INFINITY;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float t = src[min(v + i, V - 1)];
+        x[i] = v + i < V ? t : -INFINITY;
+      }
+    }
+  };
+  float m = -INFINITY;
+  for (int c = cc; c < chunks; c += 8) {
+    float x[4];
+    load4(c * 8 + e4, x);
+    m = fmaxf(fmaxf(m, fmaxf(x[0], x[1])), fmaxf(x[2], x[3]));
   }
-  const int q = (lane & 31) >> 3, e = lane & 7;
-  const float* my = q == 0 ? src[0] : q == 1 ? src[1] : q == 2 ? src[2] : src[3];
-  const float mq = q == 0 ? m[0] : q == 1 ? m[1] : q == 2 ? m[2] : m[3];
-  const bool row_ok = rr0 + q < real;
-  float* out = (isf ? w.Fp : w.Gp) + (size_t)b * R * w.Vp + tiled_off(rr0 + q, 0, chunks) + e;
-  for (int c = lane >> 5; c < chunks; c += 2) {
-    const int v = c * 8 + e;
-    const float x = my[min(v, V - 1)];
-    out[(size_t)c << 8] = (row_ok && v < V) ? fast_exp2(__builtin_fmaf(x, kLog2e, -mq)) : 0.f;
+  m = group_max<16>(m) * kLog2e;  // the 16 lanes of a row are one DPP row
+  if ((lane & 15) == 0 && row_ok) (isf ? w.mf2 + b * jg.maxT : w.mg2 + b * jg.maxU1)[row] = m;
+  float* out = (isf ? w.Fp : w.Gp) + (size_t)b * R * w.Vp + tiled_off(row, e4, chunks);
+  for (int c = cc; c < chunks; c += 8) {
+    float x[4];
+    load4(c * 8 + e4, x);
+    f4v y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = row_ok ? fast_exp2(__builtin_fmaf(x[i], kLog2e, -m)) : 0.f;  // 2^-inf = 0
+    *reinterpret_cast<f4v*>(out + ((size_t)c << 8)) = y;
   }
 }
 
@@ -1365,18 +1382,21 @@ __global__ __launch_bounds__(256) void k_joint_lse_mm(const float* __restrict__ 
   if (n_bad) atomicAdd(&w.hdr->n_fallback, n_bad);
 }
 
-// One thread per (b, t < Tp, u < U1p): {c, s*pb, s*pl, label code} of the cell (c = log2 gamma - log2 S, -inf
-// when the cell is pruned) and C = s * 2^c for the contractions (0 where pruned, flagged, or outside the lattice).
+// One block per (b, 8 frames, 32 label positions) of the padded lattice, one thread per cell: {c, s*pb, s*pl,
+// label code} (c = log2 gamma - log2 S, -inf when the cell is pruned) and C = s * 2^c for the contractions (0 where
+// pruned, flagged, or outside the lattice), written in both tiled orientations (the transposed one through LDS so
+// that both leave as runs of 32 bytes).
 __global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ labels,
                                                     const int32_t* __restrict__ in_len,
                                                     const int32_t* __restrict__ lab_len,
                                                     const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int per_b = w.Tp * w.U1p;
-  if (i >= (long long)jg.B * per_b) return;
-  const int b = (int)(i / per_b);
-  const int rem = (int)(i - (long long)b * per_b);
-  const int t = rem / w.U1p, u = rem - t * w.U1p;
+  __shared__ float tile[8][33];
+  const int ub = w.U1p >> 5, tb = w.Tp >> 3;
+  const int b = blockIdx.x / (ub * tb);
+  const int r = blockIdx.x - b * ub * tb;
+  const int t0 = (r / ub) * 8, u0 = (r - (r / ub) * ub) * 32;
+  const int tt = threadIdx.x >> 5, uu = threadIdx.x & 31;
+  const int t = t0 + tt, u = u0 + uu;
   float cm = 0.f;
   if (t < jg.maxT && u < jg.maxU1) {
     int T, U;
@@ -1392,8 +1412,12 @@ __global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ 
     if (live && !flagged) cm = sc * fast_exp2(cf.x);
     w.coef[((size_t)b * jg.maxT + t) * jg.maxU1 + u] = cf;
   }
-  w.Ctu[(size_t)b * per_b + tiled_off(t, u, w.U1p >> 3)] = cm;
-  w.Cut[(size_t)b * per_b + tiled_off(u, t, w.Tp >> 3)] = cm;
+  const size_t per_b = (size_t)w.Tp * w.U1p;
+  w.Ctu[b * per_b + tiled_off(t, u, w.U1p >> 3)] = cm;
+  tile[tt][uu] = cm;
+  __syncthreads();
+  const int u2 = threadIdx.x >> 3, t2 = threadIdx.x & 7;
+  w.Cut[b * per_b + tiled_off(u0 + u2, t0 + t2, w.Tp >> 3)] = tile[t2][u2];
 }
 
 // NT consecutive floats
@@ -1509,58 +1533,82 @@ __global__ __launch_bounds__(256) void k_joint_dg_mm(float* __restrict__ dg, con
                     dg + (size_t)mt.b * jg.maxU1 * jg.V, vec_ok, threadIdx.x & 63);
 }
 
-// Blank and label terms of d f: one wavefront per frame.  d f(t, y) -= sum over the positions u whose next
-// label is y of s*pl(t,u), and d f(t, blank) -= sum_u s*pb(t,u).  Positions with the same label are summed by
-// the lane of the first of them in a fixed order, so the result does not depend on scheduling.
-__global__ __launch_bounds__(256) void k_joint_corr_f(float* __restrict__ df, const int32_t* __restrict__ in_len,
+// Blank and label terms of d f.  d f(t, y) -= sum over the positions u whose next label is y of s*pl(t,u), and
+// d f(t, blank) -= sum_u s*pb(t,u).  One block per (utterance, 32 frames): it first links the positions that share
+// a target (labels repeat; the blank is one more target) into chains, then every wavefront takes frames, and the
+// lane of a chain's first position adds the chain up in order and subtracts it once -- no atomics, fixed order.
+__global__ __launch_bounds__(256) void k_joint_corr_f(float* __restrict__ df, const int32_t* __restrict__ labels,
+                                                      const int32_t* __restrict__ in_len,
                                                       const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
-  extern __shared__ int jcs[];  // per wave: target index [maxU1+1], value [maxU1+1]
+  extern __shared__ int jcs[];  // tgt[n], next[n], head[n], then 4 x val[n]   (n = maxU1 + 1)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = jg.maxU1 + 1;
-  int* tgt = jcs + (size_t)wv * 2 * n;
-  float* val = reinterpret_cast<float*>(tgt + n);
-  const int row = blockIdx.x * 4 + wv;
-  const bool in_rows = row < jg.B * jg.maxT;
-  const int b = in_rows ? row / jg.maxT : 0, t = in_rows ? row - b * jg.maxT : 0;
+  int* tgt = jcs;
+  int* nxt = jcs + n;
+  int* head = jcs + 2 * n;
+  float* val = reinterpret_cast<float*>(jcs + 3 * n) + (size_t)wv * n;
+  const int tblocks = (jg.maxT + 31) / 32;
+  const int b = blockIdx.x / tblocks, t0 = (blockIdx.x - b * tblocks) * 32;
   int T, U;
   utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
-  const bool active = in_rows && t < T;
-  if (active) {
-    const float4* cfrow = w.coef + ((size_t)b * jg.maxT + t) * jg.maxU1;
-    float sumb = 0.f;
-    for (int u = lane; u <= U; u += 64) {
-      const float4 cf = cfrow[u];
-      sumb += cf.y;
-      tgt[u] = (__float_as_int(cf.w) & (kJointFlagBit - 1)) - 1;  // -1: no label term
-      val[u] = cf.z;
+  if (t0 >= T) return;  // uniform over the block
+  // targets: label of position u < U (clamped like everywhere else), nothing at u = U, the blank at index U+1
+  for (int u = threadIdx.x; u <= U + 1; u += 256) {
+    int y = -1;
+    if (u < U) {
+      y = labels[(size_t)b * (jg.maxU1 - 1) + u];
+      if (y < 0 || y >= jg.V) y = 0;
+    } else if (u == U + 1) {
+      y = jg.blank;
     }
-    sumb = group_sum<64>(sumb);
-    if (lane == 0) {
-      tgt[U + 1] = jg.blank;
-      val[U + 1] = sumb;
-    }
+    tgt[u] = y;
   }
   __syncthreads();
-  if (active) {
-    float* out = df + (size_t)b * jg.dfstride + (size_t)t * jg.V;
-    for (int u = lane; u <= U + 1; u += 64) {
-      const int my = tgt[u];
-      bool leader = my >= 0;
-      for (int k = 0; k < u; ++k) leader = leader && tgt[k] != my;
-      if (leader) {
-        float s = 0.f;
-        for (int k = u; k <= U + 1; ++k) s += (tgt[k] == my) ? val[k] : 0.f;
-        out[my] -= s;
+  for (int u = threadIdx.x; u <= U + 1; u += 256) {
+    const int y = tgt[u];
+    int nx = -1, first = (y >= 0) ? 1 : 0;
+    if (y >= 0) {
+      for (int k = U + 1; k > u; --k) nx = (tgt[k] == y) ? k : nx;
+      for (int k = 0; k < u; ++k) first = (tgt[k] == y) ? 0 : first;
+    }
+    nxt[u] = nx;
+    head[u] = first;
+  }
+  __syncthreads();
+  const int t_end = min(t0 + 32, T);
+  for (int tb = t0; tb < t_end; tb += 4) {  // the same trip count in every wave: barriers inside
+    const int t = tb + wv;
+    const bool on = t < t_end;
+    if (on) {
+      const float4* cfrow = w.coef + ((size_t)b * jg.maxT + t) * jg.maxU1;
+      float sumb = 0.f;
+      for (int u = lane; u <= U; u += 64) {
+        const float4 cf = cfrow[u];
+        sumb += cf.y;
+        val[u] = cf.z;
+      }
+      sumb = group_sum<64>(sumb);
+      if (lane == 0) val[U + 1] = sumb;
+    }
+    __syncthreads();
+    if (on) {
+      float* out = df + (size_t)b * jg.dfstride + (size_t)t * jg.V;
+      for (int u = lane; u <= U + 1; u += 64) {
+        if (!head[u]) continue;
+        float sacc = 0.f;
+        for (int k = u; k >= 0; k = nxt[k]) sacc += val[k];
+        out[tgt[u]] -= sacc;
       }
     }
+    __syncthreads();
   }
 }
 
-// Blank and label terms of d g: 64 label positions per block, the frames split over the four waves.
-__global__ __launch_bounds__(256) void k_joint_corr_g(float* __restrict__ dg, const int32_t* __restrict__ labels,
-                                                      const int32_t* __restrict__ in_len,
-                                                      const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
-  __shared__ float red[2][4][64];
+// Blank and label terms of d g: 64 label positions per block, the frames split over the block's 16 waves.
+__global__ __launch_bounds__(1024) void k_joint_corr_g(float* __restrict__ dg, const int32_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ in_len,
+                                                       const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
+  __shared__ float red[2][16][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ublocks = (jg.maxU1 + 63) / 64;
   const int b = blockIdx.x / ublocks;
@@ -1570,7 +1618,7 @@ __global__ __launch_bounds__(256) void k_joint_corr_g(float* __restrict__ dg, co
   float sb = 0.f, sl = 0.f;
   if (u <= U) {
     const float4* cfb = w.coef + (size_t)b * jg.maxT * jg.maxU1 + u;
-    for (int t = wv; t < T; t += 4) {
+    for (int t = wv; t < T; t += 16) {
       const float4 cf = cfb[(size_t)t * jg.maxU1];
       sb += cf.y;
       sl += cf.z;
@@ -1580,8 +1628,13 @@ __global__ __launch_bounds__(256) void k_joint_corr_g(float* __restrict__ dg, co
   red[1][wv][lane] = sl;
   __syncthreads();
   if (wv == 0 && u <= U && T > 0) {
-    sb = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-    sl = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    sb = 0.f;
+    sl = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      sb += red[0][i][lane];
+      sl += red[1][i][lane];
+    }
     float* out = dg + ((size_t)b * jg.maxU1 + u) * jg.V;
     out[jg.blank] -= sb;
     if (u < U) {
@@ -2007,7 +2060,10 @@ int launch_joint_forward(const JointCall& c, float* costs, hipStream_t st) {
   const Ws& w = c.w;
   k_init<<<1, 64, 0, st>>>(w, 0);
   const int groups = jg.B * ((w.Tp + w.U1p) / 4);
-  k_joint_prep<<<(groups + 3) / 4, 256, 0, st>>>(c.f, c.g, jg, w);
+  const bool rows16 = jg.V % 4 == 0 && jg.fstride % 4 == 0 && reinterpret_cast<uintptr_t>(c.f) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(c.g) % 16 == 0;
+  if (rows16) k_joint_prep<true><<<(groups + 3) / 4, 256, 0, st>>>(c.f, c.g, jg, w);
+  else k_joint_prep<false><<<(groups + 3) / 4, 256, 0, st>>>(c.f, c.g, jg, w);
   const long long ncell = (long long)jg.B * jg.maxT * jg.maxU1;
   k_joint_gather<<<(unsigned)((ncell + 255) / 256), 256, 0, st>>>(c.f, c.g, c.labels, c.in_len, c.lab_len, jg, w);
   const int mt = w.Tp / 32;
@@ -2026,8 +2082,8 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
   const JointGeom& jg = c.jg;
   const Ws& w = c.w;
   const int ke = joint_ke(jg.V);
-  const long long padded = (long long)jg.B * w.Tp * w.U1p;
-  k_joint_coef<<<(unsigned)((padded + 255) / 256), 256, 0, st>>>(c.labels, c.in_len, c.lab_len, grad_scale, jg, w);
+  k_joint_coef<<<(unsigned)(jg.B * (w.Tp / 8) * (w.U1p / 32)), 256, 0, st>>>(c.labels, c.in_len, c.lab_len, grad_scale,
+                                                                             jg, w);
   const int mt = w.Tp / 32, mu = w.U1p / 32;
   const int nt = w.Vp <= 32 ? 1 : w.Vp <= 64 ? 2 : 4;
   // results may leave as vectors of nt floats when every row of d f / d g starts on a multiple of nt floats
@@ -2046,9 +2102,9 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
     k_joint_df_mm<4><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
     k_joint_dg_mm<4><<<mm_blocks(jg.B, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
   }
-  const size_t corr_lds = sizeof(int) * 4 * 2 * (size_t)(jg.maxU1 + 1);
-  k_joint_corr_f<<<(jg.B * jg.maxT + 3) / 4, 256, corr_lds, st>>>(df, c.in_len, c.lab_len, jg, w);
-  k_joint_corr_g<<<jg.B * ((jg.maxU1 + 63) / 64), 256, 0, st>>>(dg, c.labels, c.in_len, c.lab_len, jg, w);
+  const size_t corr_lds = sizeof(int) * 7 * (size_t)(jg.maxU1 + 1);
+  k_joint_corr_f<<<jg.B * ((jg.maxT + 31) / 32), 256, corr_lds, st>>>(df, c.labels, c.in_len, c.lab_len, jg, w);
+  k_joint_corr_g<<<jg.B * ((jg.maxU1 + 63) / 64), 1024, 0, st>>>(dg, c.labels, c.in_len, c.lab_len, jg, w);
 #define JGRID_T(TT) dim3((unsigned)(jg.B * ((((jg.maxT + (TT)-1) / (TT)) + 3) / 4)))
 #define JGRID_U(UU) dim3((unsigned)(jg.B * ((((jg.maxU1 + (UU)-1) / (UU)) + 3) / 4)))
   RNNT_JOINT_DISPATCH(k_joint_fix_f, ke, JGRID_T, 2, 1, 1, c.f, c.g, df, c.in_len, c.lab_len, grad_scale, jg, w);
