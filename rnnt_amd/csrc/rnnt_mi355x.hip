@@ -1330,24 +1330,37 @@ __global__ __launch_bounds__(256) void k_joint_lse_mm(const float* __restrict__ 
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  f4v a = ld4(ap), bb[NT];
+  // Two register sets of two column chunks (16 v) each, used alternately: the loads of one set are in flight
+  // during the 8*NT MFMAs of the other (the number of chunks is a multiple of 4).
+  f4v a0[2], a1[2], b0[NT][2], b1[NT][2];
+  auto load_set = [&](int c, f4v (&a)[2], f4v (&bs)[NT][2]) {
+    const size_t o = (size_t)min(c, chunks - 2) << 8;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) bb[j] = ld4(bp[j]);
-  for (int c = 0; c < chunks; ++c) {
-    const size_t on = (size_t)min(c + 1, chunks - 1) << 8;
-    const f4v an = ld4(ap + on);
-    f4v bn[NT];
+    for (int s2 = 0; s2 < 2; ++s2) {
+      a[s2] = ld4(ap + o + ((size_t)s2 << 8));
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bn[j] = ld4(bp[j] + on);
+      for (int j = 0; j < NT; ++j) bs[j][s2] = ld4(bp[j] + o + ((size_t)s2 << 8));
+    }
+  };
+  auto mfma_set = [&](const f4v (&a)[2], const f4v (&bs)[NT][2]) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2][i], bs[j][s2][i], acc[j], 0, 0, 0);
+  };
+  load_set(0, a0, b0);
+  for (int c = 0; c < chunks; c += 4) {
+    load_set(c + 2, a1, b1);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j][i], acc[j], 0, 0, 0);
+    mfma_set(a0, b0);
     __builtin_amdgcn_sched_barrier(0);
-    a = an;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bb[j] = bn[j];
+    load_set(c + 4, a0, b0);  // past the end: re-reads the last chunks, unused
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_set(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
   float4* frame0 = w.rec + ((size_t)b * (jg.maxT + 2) + 1) * jg.maxU1;
   int n_bad = 0;
@@ -1456,27 +1469,35 @@ __device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   auto b_off = [&](int k0, int i) { return ((size_t)(k0 >> 5) * chunks << 8) + (((k0 & 31) + i) << 3); };
+  // Two register sets used alternately: the loads of one are in flight during the 4*NT MFMAs of the other.
+  f4v a0, a1;
+  vecn bv0[4], bv1[4];
+  auto load_set = [&](int k0, f4v& a, vecn (&bv)[4]) {
+    a = ld4(ap + ((size_t)(k0 >> 3) << 8));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const vecn*>(bp + b_off(k0, i));
+  };
+  auto mfma_set = [&](const f4v& a, const vecn (&bv)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], fvec_get<NT>(bv[i], j), acc[j], 0, 0, 0);
+  };
   if (kmax > 0) {
-    f4v a = ld4(ap);
-    vecn bv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const vecn*>(bp + b_off(0, i));
-    for (int k0 = 0; k0 < kmax; k0 += 8) {
-      const int kn = min(k0 + 8, kmax - 8);
-      const f4v an = ld4(ap + ((size_t)(kn >> 3) << 8));
-      vecn bn[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) bn[i] = *reinterpret_cast<const vecn*>(bp + b_off(kn, i));
+    load_set(0, a0, bv0);
+    for (int k0 = 0; k0 < kmax; k0 += 16) {
+      const bool second = k0 + 8 < kmax;  // uniform
+      load_set(second ? k0 + 8 : k0, a1, bv1);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], fvec_get<NT>(bv[i], j), acc[j], 0, 0, 0);
+      mfma_set(a0, bv0);
       __builtin_amdgcn_sched_barrier(0);
-      a = an;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) bv[i] = bn[i];
+      if (second) {
+        load_set(min(k0 + 16, kmax - 8), a0, bv0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(a1, bv1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 #pragma unroll
