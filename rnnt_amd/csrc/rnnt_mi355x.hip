@@ -1155,6 +1155,7 @@ struct JointGeom {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr float kJointMinSum = 5.421010862427522e-20f;  // 2^-64: below this the linear-domain sum is not trusted
+constexpr int kMmSets = 2;  // operand register sets per wavefront in the contraction loops
 constexpr int kJointFlagBit = 1 << 20;                  // label code = (label + 1) | flag; labels < 4096
 
 __device__ __forceinline__ f4v ld4(const float* p) { return *reinterpret_cast<const f4v*>(p); }
@@ -1331,68 +1332,95 @@ __global__ __launch_bounds__(256) void k_joint_lse_mm(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   // Two register sets of two column chunks (16 v) each, used alternately: the loads of one set are in flight
-  // during the 8*NT MFMAs of the other (the number of chunks is a multiple of 4).
-  f4v a0[2], a1[2], b0[NT][2], b1[NT][2];
-  auto load_set = [&](int c, f4v (&a)[2], f4v (&bs)[NT][2]) {
-    const size_t o = (size_t)min(c, chunks - 2) << 8;
+  // during the 8*NT MFMAs of the other.  (Four sets in flight measured slower: fewer resident waves.)
+  const int nsets = chunks >> 1;
+  f4v as[kMmSets][2], bs[kMmSets][NT][2];
+  auto load_set = [&](int set, f4v (&a)[2], f4v (&bq)[NT][2]) {
+    const size_t o = (size_t)min(set, nsets - 1) << 9;  // past the end: re-reads the last set, unused
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       a[s2] = ld4(ap + o + ((size_t)s2 << 8));
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bs[j][s2] = ld4(bp[j] + o + ((size_t)s2 << 8));
+      for (int j = 0; j < NT; ++j) bq[j][s2] = ld4(bp[j] + o + ((size_t)s2 << 8));
     }
   };
-  auto mfma_set = [&](const f4v (&a)[2], const f4v (&bs)[NT][2]) {
+  auto mfma_set = [&](const f4v (&a)[2], const f4v (&bq)[NT][2]) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2][i], bs[j][s2][i], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2][i], bq[j][s2][i], acc[j], 0, 0, 0);
   };
-  load_set(0, a0, b0);
-  for (int c = 0; c < chunks; c += 4) {
-    load_set(c + 2, a1, b1);
+  load_set(0, as[0], bs[0]);
+  for (int s0 = 0; s0 < nsets; s0 += 2) {  // nsets is even; no branch inside the body, so the loads stay where they are
+    load_set(s0 + 1, as[1], bs[1]);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_set(a0, b0);
+    mfma_set(as[0], bs[0]);
     __builtin_amdgcn_sched_barrier(0);
-    load_set(c + 4, a0, b0);  // past the end: re-reads the last chunks, unused
+    load_set(s0 + 2, as[0], bs[0]);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_set(a1, b1);
+    mfma_set(as[1], bs[1]);
     __builtin_amdgcn_sched_barrier(0);
   }
+  // Records of the tile's cells: {x - ls, y - ls, ls, flag}.  All 16 records of an MFMA tile are loaded first
+  // (lanes without a cell re-read a neighbouring one), then updated and stored, so that the memory round trips
+  // overlap.  Cells whose sum underflowed are left for the slow loop below.
   float4* frame0 = w.rec + ((size_t)b * (jg.maxT + 2) + 1) * jg.maxU1;
-  int n_bad = 0;
+  unsigned badmask = 0;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
+    const int u = u0 + 32 * j + l32;
+    const int uc = min(u, U);
+    float4 rc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rc[r] = frame0[(size_t)min(t0 + mm_row(r, lane), T - 1) * jg.maxU1 + uc];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int t = t0 + mm_row(r, lane), u = u0 + 32 * j + l32;
+      const int t = t0 + mm_row(r, lane);
       const bool valid = t < T && u <= U;
       const float S = acc[j][r];
-      float ls = fast_log2(S);
       const bool bad = valid && !(S >= kJointMinSum);
+      badmask |= bad ? (1u << (16 * j + r)) : 0u;
+      if (valid && !bad) {
+        const float ls = fast_log2(S);
+        float4 o = rc[r];
+        o.x -= ls;
+        o.y = (u < U) ? o.y - ls : kNegF;
+        o.z = ls;
+        o.w = 0.f;
+        frame0[(size_t)t * jg.maxU1 + u] = o;
+      }
+    }
+  }
+  if (__ballot(badmask != 0)) {  // rare: redo those cells with the exact maximum, one at a time, all lanes helping
+    int n_bad = 0;
+    for (int q = 0; q < 16 * NT; ++q) {
+      const int j = q >> 4, r = q & 15;
+      const int t = t0 + mm_row(r, lane), u = u0 + 32 * j + l32;
+      const bool bad = (badmask >> q) & 1u;
       unsigned long long m = __ballot(bad);
-      while (m) {  // rare: redo the cell with the exact maximum
+      float ls = 0.f;
+      while (m) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1;
         const float e = joint_exact_ls(f, g, jg, w, b, __shfl(t, src), __shfl(u, src), lane);
         if (lane == src) ls = e;
       }
-      n_bad += bad ? 1 : 0;
-      if (valid) {
+      if (bad) {
         float4* cell = frame0 + (size_t)t * jg.maxU1 + u;
-        float4 rc = *cell;
-        rc.x -= ls;
-        rc.y = (u < U) ? rc.y - ls : kNegF;
-        rc.z = ls;
-        rc.w = bad ? 1.f : 0.f;
-        *cell = rc;
+        float4 o = *cell;
+        o.x -= ls;
+        o.y = (u < U) ? o.y - ls : kNegF;
+        o.z = ls;
+        o.w = 1.f;
+        *cell = o;
+        ++n_bad;
       }
     }
+    if (n_bad) atomicAdd(&w.hdr->n_fallback, n_bad);
   }
-  if (n_bad) atomicAdd(&w.hdr->n_fallback, n_bad);
 }
 
 // One block per (b, 8 frames, 32 label positions) of the padded lattice, one thread per cell: {c, s*pb, s*pl,
@@ -1500,24 +1528,30 @@ __device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, 
       }
     }
   }
+  // all 16 element-wise factors are loaded before the first store (rows past the end re-read the last one);
+  // requesting them ahead of the K loop measured slower (64 more registers, fewer resident waves)
+  vecn e[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    e[r] = *reinterpret_cast<const vecn*>(e_base + tiled_off(min(m0 + mm_row(r, lane), m_real - 1), col, chunks));
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + mm_row(r, lane);
-    if (m >= m_real) continue;
-    const vecn e = *reinterpret_cast<const vecn*>(e_base + tiled_off(m, col, chunks));
     float* o = out + (size_t)m * V + col;
-    if (vec_ok && col + NT <= V) {
-      vecn res;
-      if constexpr (NT == 1) res = e * acc[0][r];
-      else {
+    if (m < m_real) {
+      if (vec_ok && col + NT <= V) {
+        vecn res;
+        if constexpr (NT == 1) res = e[r] * acc[0][r];
+        else {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) res[j] = e[j] * acc[j][r];
+          for (int j = 0; j < NT; ++j) res[j] = e[r][j] * acc[j][r];
+        }
+        *reinterpret_cast<vecn*>(o) = res;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          if (col + j < V) o[j] = fvec_get<NT>(e[r], j) * acc[j][r];
       }
-      *reinterpret_cast<vecn*>(o) = res;
-    } else {
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        if (col + j < V) o[j] = fvec_get<NT>(e, j) * acc[j][r];
     }
   }
 }
