@@ -125,7 +125,9 @@ int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, con
  * The backward writes d(sum_b grad_scale[b]*cost_b)/df and /dg directly (what
  * TensorFlow obtains by reducing the [B,T,U+1,V] gradient over u and over t,
  * util.py:107-109).  Needs the larger workspace of
- * rnnt_mi355x_joint_workspace_bytes; V <= 4096.  rnnt_mi355x_reduce_scalars
+ * rnnt_mi355x_joint_workspace_bytes (which depends on V: it holds exp(f - max f)
+ * and exp(g - max g), the operands of the matrix-core contractions the sums over
+ * V, u and t are computed as); V <= 4096.  rnnt_mi355x_reduce_scalars
  * after a joint backward returns the cost sum and 0 for the norm. */
 int rnnt_mi355x_joint_workspace_bytes(int B, int maxT, int maxU1, int V, size_t* out_bytes);
 int rnnt_mi355x_joint_forward(const float* f, size_t f_batch_stride, const float* g, const int32_t* labels,

@@ -1589,24 +1589,39 @@ __global__ __launch_bounds__(256) void k_joint_dg_mm(float* __restrict__ dg, con
 }
 
 // Blank and label terms of d f.  d f(t, y) -= sum over the positions u whose next label is y of s*pl(t,u), and
-// d f(t, blank) -= sum_u s*pb(t,u).  One block per (utterance, 32 frames): it first links the positions that share
-// a target (labels repeat; the blank is one more target) into chains, then every wavefront takes frames, and the
-// lane of a chain's first position adds the chain up in order and subtracts it once -- no atomics, fixed order.
+// d f(t, blank) -= sum_u s*pb(t,u).  One block per (utterance, fb frames): it links the positions that share a
+// target (labels repeat; the blank is one more target) into chains, then one thread per (frame, first position of
+// a chain) adds the chain up in order and subtracts it once -- no atomics, fixed order.
 __global__ __launch_bounds__(256) void k_joint_corr_f(float* __restrict__ df, const int32_t* __restrict__ labels,
                                                       const int32_t* __restrict__ in_len,
-                                                      const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
-  extern __shared__ int jcs[];  // tgt[n], next[n], head[n], then 4 x val[n]   (n = maxU1 + 1)
+                                                      const int32_t* __restrict__ lab_len, JointGeom jg, Ws w,
+                                                      int fb) {
+  extern __shared__ int jcs[];  // tgt[n], next[n], head[n], then val[fb][n]   (n = maxU1 + 1)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = jg.maxU1 + 1;
   int* tgt = jcs;
   int* nxt = jcs + n;
   int* head = jcs + 2 * n;
-  float* val = reinterpret_cast<float*>(jcs + 3 * n) + (size_t)wv * n;
-  const int tblocks = (jg.maxT + 31) / 32;
-  const int b = blockIdx.x / tblocks, t0 = (blockIdx.x - b * tblocks) * 32;
+  float* val = reinterpret_cast<float*>(jcs + 3 * n);
+  const int tblocks = (jg.maxT + fb - 1) / fb;
+  const int b = blockIdx.x / tblocks, t0 = (blockIdx.x - b * tblocks) * fb;
   int T, U;
   utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
   if (t0 >= T) return;  // uniform over the block
+  // the label terms of the block's frames (all requested before anything waits), blank sums at U+1
+  const int nrow = min(fb, T - t0);
+  for (int i = wv; i < nrow; i += 4) {
+    const float4* cfrow = w.coef + ((size_t)b * jg.maxT + t0 + i) * jg.maxU1;
+    float* vr = val + (size_t)i * n;
+    float sumb = 0.f;
+    for (int u = lane; u <= U; u += 64) {
+      const float4 cf = cfrow[u];
+      sumb += cf.y;
+      vr[u] = cf.z;
+    }
+    sumb = group_sum<64>(sumb);
+    if (lane == 0) vr[U + 1] = sumb;
+  }
   // targets: label of position u < U (clamped like everywhere else), nothing at u = U, the blank at index U+1
   for (int u = threadIdx.x; u <= U + 1; u += 256) {
     int y = -1;
@@ -1630,32 +1645,14 @@ __global__ __launch_bounds__(256) void k_joint_corr_f(float* __restrict__ df, co
     head[u] = first;
   }
   __syncthreads();
-  const int t_end = min(t0 + 32, T);
-  for (int tb = t0; tb < t_end; tb += 4) {  // the same trip count in every wave: barriers inside
-    const int t = tb + wv;
-    const bool on = t < t_end;
-    if (on) {
-      const float4* cfrow = w.coef + ((size_t)b * jg.maxT + t) * jg.maxU1;
-      float sumb = 0.f;
-      for (int u = lane; u <= U; u += 64) {
-        const float4 cf = cfrow[u];
-        sumb += cf.y;
-        val[u] = cf.z;
-      }
-      sumb = group_sum<64>(sumb);
-      if (lane == 0) val[U + 1] = sumb;
-    }
-    __syncthreads();
-    if (on) {
-      float* out = df + (size_t)b * jg.dfstride + (size_t)t * jg.V;
-      for (int u = lane; u <= U + 1; u += 64) {
-        if (!head[u]) continue;
-        float sacc = 0.f;
-        for (int k = u; k >= 0; k = nxt[k]) sacc += val[k];
-        out[tgt[u]] -= sacc;
-      }
-    }
-    __syncthreads();
+  // one thread per (frame, chain head): add the chain up in order, subtract it once
+  for (int idx = threadIdx.x; idx < nrow * (U + 2); idx += 256) {
+    const int i = idx / (U + 2), u = idx - i * (U + 2);
+    if (!head[u]) continue;
+    const float* vr = val + (size_t)i * n;
+    float sacc = 0.f;
+    for (int k = u; k >= 0; k = nxt[k]) sacc += vr[k];
+    df[(size_t)b * jg.dfstride + (size_t)(t0 + i) * jg.V + tgt[u]] -= sacc;
   }
 }
 
@@ -2157,8 +2154,9 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
     k_joint_df_mm<4><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
     k_joint_dg_mm<4><<<mm_blocks(jg.B, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
   }
-  const size_t corr_lds = sizeof(int) * 7 * (size_t)(jg.maxU1 + 1);
-  k_joint_corr_f<<<jg.B * ((jg.maxT + 31) / 32), 256, corr_lds, st>>>(df, c.labels, c.in_len, c.lab_len, jg, w);
+  const int fb = jg.maxU1 <= 128 ? 32 : jg.maxU1 <= 256 ? 16 : 8;  // frames per block: (3 + fb) * (maxU1 + 1) words of LDS
+  const size_t corr_lds = sizeof(int) * (3 + fb) * (size_t)(jg.maxU1 + 1);
+  k_joint_corr_f<<<jg.B * ((jg.maxT + fb - 1) / fb), 256, corr_lds, st>>>(df, c.labels, c.in_len, c.lab_len, jg, w, fb);
   k_joint_corr_g<<<jg.B * ((jg.maxU1 + 63) / 64), 1024, 0, st>>>(dg, c.labels, c.in_len, c.lab_len, jg, w);
 #define JGRID_T(TT) dim3((unsigned)(jg.B * ((((jg.maxT + (TT)-1) / (TT)) + 3) / 4)))
 #define JGRID_U(UU) dim3((unsigned)(jg.B * ((((jg.maxU1 + (UU)-1) / (UU)) + 3) / 4)))
