@@ -138,6 +138,26 @@ int rnnt_mi355x_joint_backward(const float* f, size_t f_batch_stride, const floa
                                int blank, const float* grad_scale, float* df, size_t df_batch_stride, float* dg,
                                void* workspace, void* hip_stream);
 
+/* ---- first layer of the fully-connected joint --------------------------------
+ * The reference's FC-joint model tiles the encoder output [B,T,He] and the
+ * prediction-network output [B,U+1,Hd] into [B,T,U+1,He+Hd]
+ * (Util.concatenate_lambda, reference rnnt/base/util.py:76-90) and applies
+ * Dense(H, tanh) to it (first layer of KerasModel.get_fc, reference
+ * rnnt/keras_model.py:83-104).  Because that layer is linear in the
+ * concatenation, the caller computes pe = enc * W1[:He] ([B,T,H]) and
+ * pd = dec * W1[He:] + b1 ([B,U1,H]) with two small matrix products and these
+ * entry points do the rest without the tiled tensor:
+ *   forward : h[b,t,u,:] = tanh(pe[b,t,:] + pd[b,u,:])              h: [B,T,U1,H]
+ *   backward: d = dh * (1 - h^2) (h recomputed from pe, pd; dh: [B,T,U1,H]),
+ *             dpe[b,t,:] = sum_u d, dpd[b,u,:] = sum_t d            (fixed summation order)
+ * All tensors float32, contiguous.  The backward needs
+ * rnnt_mi355x_fc_joint_workspace_bytes of scratch.  H <= 1536. */
+int rnnt_mi355x_fc_joint_workspace_bytes(int B, int T, int U1, int H, size_t* out_bytes);
+int rnnt_mi355x_fc_joint_forward(const float* pe, const float* pd, int B, int T, int U1, int H, float* h,
+                                 void* hip_stream);
+int rnnt_mi355x_fc_joint_backward(const float* pe, const float* pd, const float* dh, int B, int T, int U1, int H,
+                                  float* dpe, float* dpd, void* workspace, void* hip_stream);
+
 /* out2[0] = sum_b costs[b], out2[1] = sum of squared gradient elements of the
  * last backward on this workspace (both float64, device memory).  These are
  * the two scalars a data-parallel caller all-reduces: the batch loss of

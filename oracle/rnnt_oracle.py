@@ -226,6 +226,44 @@ def rnnt_lambda_func_v2(acts, labels, input_length, label_length, blank_label=39
     return costs, d_acts
 
 
+def concatenate_lambda(y_trans, y_pred):
+    """Float64 restatement of ``Util.concatenate_lambda`` (reference
+    util.py:76-90): tile both outputs and concatenate -> [B,T,U+1,He+Hd]."""
+    y_trans = np.asarray(y_trans, dtype=np.float64)
+    y_pred = np.asarray(y_pred, dtype=np.float64)
+    T, U1 = y_trans.shape[1], y_pred.shape[1]
+    ex_t = np.tile(y_trans[:, :, None, :], (1, 1, U1, 1))  # util.py:83-84
+    ex_p = np.tile(y_pred[:, None, :, :], (1, T, 1, 1))    # util.py:87-88
+    return np.concatenate([ex_t, ex_p], axis=-1)            # util.py:90
+
+
+def fc_joint_loss_and_grads(y_trans, y_pred, weights, labels, input_length, label_length, blank_label=39,
+                            grad_scale=None):
+    """Float64 restatement of the FC-joint model's loss head (reference
+    keras_model.py:169-188): concatenate_lambda (util.py:76-90) -> get_fc
+    (keras_model.py:83-104: Dense+tanh ... Dense linear, Keras kernels [in,out])
+    -> rnnt_lambda_func_v2 (util.py:53-74), literally -- the tiled tensor IS
+    built here.  Returns (costs[B], d y_trans, d y_pred, [(d kernel, d bias), ...])."""
+    weights = [(np.asarray(k, np.float64), np.asarray(b, np.float64)) for k, b in weights]
+    x0 = concatenate_lambda(y_trans, y_pred)
+    xs = [x0]
+    for li, (k, b) in enumerate(weights):
+        z = xs[-1] @ k + b
+        xs.append(z if li == len(weights) - 1 else np.tanh(z))  # keras_model.py:91-92
+    costs, d = rnnt_lambda_func_v2(xs[-1], labels, input_length, label_length, blank_label, grad_scale)
+    dws = [None] * len(weights)
+    for li in range(len(weights) - 1, -1, -1):
+        k, _ = weights[li]
+        if li != len(weights) - 1:
+            d = d * (1.0 - xs[li + 1] ** 2)
+        xin = xs[li].reshape(-1, k.shape[0])
+        d2 = d.reshape(-1, k.shape[1])
+        dws[li] = (xin.T @ d2, d2.sum(axis=0))
+        d = d @ k.T
+    He = np.asarray(y_trans).shape[2]
+    return costs, d[..., :He].sum(axis=2), d[..., He:].sum(axis=1), dws
+
+
 # ---------------------------------------------------------------------------
 # Independent second opinions used to pin the oracle itself.
 # ---------------------------------------------------------------------------

@@ -38,6 +38,9 @@ _SIGNATURES = {
     "rnnt_mi355x_joint_workspace_bytes": (ctypes.c_int, [_i, _i, _i, _i, ctypes.POINTER(_sz)]),
     "rnnt_mi355x_joint_forward": (ctypes.c_int, [_vp, _sz] + [_vp] * 4 + _META + [_vp, _vp, _vp]),
     "rnnt_mi355x_joint_backward": (ctypes.c_int, [_vp, _sz] + [_vp] * 4 + _META + [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "rnnt_mi355x_fc_joint_workspace_bytes": (ctypes.c_int, [_i, _i, _i, _i, ctypes.POINTER(_sz)]),
+    "rnnt_mi355x_fc_joint_forward": (ctypes.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "rnnt_mi355x_fc_joint_backward": (ctypes.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rnnt_mi355x_reduce_scalars": (ctypes.c_int, [_vp, _i, _vp, _vp, _vp]),
     "rnnt_mi355x_read_status": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
     "rnnt_mi355x_status_string": (ctypes.c_char_p, [_i]),
@@ -80,6 +83,12 @@ def status_string(rc: int) -> str:
 def check(rc: int, what: str) -> None:
     if rc != OK:
         raise RuntimeError(f"{what}: {status_string(rc)} (status {rc})")
+
+
+def fc_joint_workspace_bytes(B: int, T: int, U1: int, H: int) -> int:
+    out = _sz(0)
+    check(lib().rnnt_mi355x_fc_joint_workspace_bytes(B, T, U1, H, ctypes.byref(out)), "rnnt_mi355x_fc_joint_workspace_bytes")
+    return int(out.value)
 
 
 def joint_workspace_bytes(B: int, maxT: int, maxU1: int, V: int) -> int:

@@ -1,4 +1,4 @@
-"""Compiles rnnt_amd/csrc/rnnt_mi355x.hip into librnnt_mi355x.so for gfx950.
+"""Compiles rnnt_amd/csrc/*.hip into librnnt_mi355x.so for gfx950.
 
 hipcc cross-compiles without a GPU, so this runs in a CPU-only container; the
 built library stays in-tree (git-ignored) and travels with the source tree.
@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SRC = os.path.join(CSRC, "rnnt_mi355x.hip")
+SOURCES = [os.path.join(CSRC, "rnnt_mi355x.hip"), os.path.join(CSRC, "fc_joint.hip")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rnnt_mi355x.h")
 LIB = os.path.join(CSRC, "librnnt_mi355x.so")
 
@@ -27,14 +27,14 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in (SRC, HEADER))
+    return any(os.path.getmtime(p) > t for p in (*SOURCES, HEADER))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-o", LIB, SRC]
+           "-o", LIB, *SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

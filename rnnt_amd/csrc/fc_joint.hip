@@ -1,0 +1,223 @@
+// First layer of the reference's fully-connected joint network for MI355X (gfx950).
+//
+// The reference's FC-joint model tiles the encoder output [B,T,He] and the
+// prediction-network output [B,U+1,Hd] into one [B,T,U+1,He+Hd] tensor
+// (Util.concatenate_lambda, reference rnnt/base/util.py:76-90) and runs a stack
+// of Dense layers over it (KerasModel.get_fc, reference rnnt/keras_model.py:
+// 83-104; tanh on all but the last).  The first Dense layer is linear in the
+// concatenation, so
+//     tanh(concat(e_t, d_u) W1 + b1) = tanh(e_t W1[:He] + (d_u W1[He:] + b1))
+// and the tiled tensor never needs to exist: two small matrix products give
+// pe[B,T,H] and pd[B,U+1,H]; the kernels here do the broadcast, the tanh and,
+// backwards, the two reductions of the upstream gradient.
+//
+//   k_fcj_fwd        h[b,t,u,:] = tanh(pe[b,t,:] + pd[b,u,:])          (write bound)
+//   k_fcj_bwd        one pass over dh[B,T,U+1,H]: d = dh * (1 - h^2) with h recomputed,
+//                    dpe[b,t,:] = sum_u d (through an LDS tile, fixed order),
+//                    per-(b, frame chunk) partial sums of d over t
+//   k_fcj_bwd_reduce dpd[b,u,:] = sum over the frame chunks, in order
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/rnnt_mi355x.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kFrames = 8;          // frames per block of the backward pass
+constexpr int kTileFloats = 8192;   // LDS tile of the backward pass: label positions x H floats
+constexpr float kTwoLog2e = 2.885390081777927f;
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// tanh(x) = 1 - 2 / (2^(2x log2 e) + 1); exact limits at +-inf, relative error ~2e-7
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * kTwoLog2e);
+  return 1.f - 2.f / (e + 1.f);
+}
+
+// rows of pd (label positions) per LDS tile, and tiles per utterance
+inline int tile_rows(int U1, int H) {
+  int r = kTileFloats / H;
+  if (r < 1) r = 1;
+  return r < U1 ? r : U1;
+}
+
+// h[b,t,i] = tanh(pe[b,t, i % H] + pd[b, i]) for i in [0, U1*H): both the output row of (b,t) and pd[b] are
+// contiguous in i.  One block per (b, t); VEC = 4 when H % 4 == 0 and the pointers are 16-byte aligned.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_fcj_fwd(const float* __restrict__ pe, const float* __restrict__ pd,
+                                                    float* __restrict__ h, int T, int U1, int H) {
+  const int bt = blockIdx.x;
+  const int b = bt / T;
+  const int n = U1 * H / VEC, hv = H / VEC;
+  const float* per = pe + (size_t)bt * H;
+  const float* pdb = pd + (size_t)b * U1 * H;
+  float* out = h + (size_t)bt * U1 * H;
+  int hi = threadIdx.x % hv;
+  const int hstep = kBlock % hv;
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    if constexpr (VEC == 4) {
+      const f4v a = *reinterpret_cast<const f4v*>(per + 4 * hi);
+      const f4v c = *reinterpret_cast<const f4v*>(pdb + 4 * (size_t)i);
+      f4v r;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] = tanh_fast(a[k] + c[k]);
+      __builtin_nontemporal_store(r, reinterpret_cast<f4v*>(out + 4 * (size_t)i));
+    } else {
+      __builtin_nontemporal_store(tanh_fast(per[hi] + pdb[i]), out + i);
+    }
+    hi += hstep;
+    if (hi >= hv) hi -= hv;
+  }
+}
+
+// One block per (b, chunk of kFrames frames).  For every tile of `rows` label positions and every frame of the
+// chunk: d = dh * (1 - tanh^2(pe + pd)) goes to an LDS tile [rows][H]; the threads keep the sums over the
+// chunk's frames of their own tile elements in registers (-> partial[b][chunk][u][h]) and, after a barrier,
+// thread h adds the tile's column h up in row order (-> dpe[b][t][h], accumulated over the tiles in LDS).
+template <int NACC>
+__global__ __launch_bounds__(kBlock) void k_fcj_bwd(const float* __restrict__ pe, const float* __restrict__ pd,
+                                                    const float* __restrict__ dh, float* __restrict__ dpe,
+                                                    float* __restrict__ partial, int T, int U1, int H, int rows,
+                                                    int nchunk) {
+  extern __shared__ float lds[];  // tile[rows*H], dpe_acc[kFrames*H], pe_s[kFrames*H]
+  float* tile = lds;
+  float* dpe_acc = lds + (size_t)rows * H;
+  float* pe_s = dpe_acc + kFrames * H;
+  const int b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk;
+  const int t0 = chunk * kFrames, nt = min(kFrames, T - t0);
+  for (int i = threadIdx.x; i < kFrames * H; i += kBlock) {
+    dpe_acc[i] = 0.f;
+    pe_s[i] = (i < nt * H) ? pe[((size_t)b * T + t0) * H + i] : 0.f;
+  }
+  __syncthreads();
+  const float* pdb = pd + (size_t)b * U1 * H;
+  float* part = partial + ((size_t)b * nchunk + chunk) * U1 * H;
+  for (int u0 = 0; u0 < U1; u0 += rows) {
+    const int nr = min(rows, U1 - u0), n = nr * H;
+    float acc[NACC], pdv[NACC];
+    int hcol[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+      const int i = threadIdx.x + k * kBlock;
+      acc[k] = 0.f;
+      pdv[k] = (i < n) ? pdb[(size_t)u0 * H + i] : 0.f;
+      hcol[k] = i % H;
+    }
+    for (int tt = 0; tt < nt; ++tt) {
+      const float* src = dh + (((size_t)b * T + t0 + tt) * U1 + u0) * H;
+      float dv[NACC];
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) {
+        const int i = threadIdx.x + k * kBlock;
+        dv[k] = (i < n) ? __builtin_nontemporal_load(src + i) : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) {
+        const int i = threadIdx.x + k * kBlock;
+        const float hh = tanh_fast(pe_s[tt * H + hcol[k]] + pdv[k]);
+        const float d = dv[k] * (1.f - hh * hh);
+        acc[k] += d;
+        if (i < n) tile[i] = d;
+      }
+      __syncthreads();
+      for (int hc = threadIdx.x; hc < H; hc += kBlock) {
+        float s = dpe_acc[tt * H + hc];
+        for (int r = 0; r < nr; ++r) s += tile[r * H + hc];
+        dpe_acc[tt * H + hc] = s;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+      const int i = threadIdx.x + k * kBlock;
+      if (i < n) part[(size_t)u0 * H + i] = acc[k];
+    }
+  }
+  for (int i = threadIdx.x; i < nt * H; i += kBlock) dpe[((size_t)b * T + t0) * H + i] = dpe_acc[i];
+}
+
+// dpd[b][i] = sum over the frame chunks of partial[b][chunk][i], i in [0, U1*H)
+__global__ __launch_bounds__(kBlock) void k_fcj_bwd_reduce(const float* __restrict__ partial,
+                                                           float* __restrict__ dpd, int per_b, int nchunk,
+                                                           long long total) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= total) return;
+  const long long b = i / per_b;
+  const int r = (int)(i - b * per_b);
+  const float* p = partial + (size_t)b * nchunk * per_b + r;
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += p[(size_t)c * per_b];
+  dpd[i] = s;
+}
+
+constexpr int kMaxH = 1536;  // tile + two [kFrames][H] arrays must fit the 160 KiB of LDS
+
+int check_dims(int B, int T, int U1, int H) {
+  if (B < 1 || T < 1 || U1 < 1 || H < 1) return RNNT_MI355X_INVALID_VALUE;
+  if (H > kMaxH) return RNNT_MI355X_UNSUPPORTED_SIZE;
+  if ((long long)B * T >= (1LL << 31) || (long long)U1 * H >= (1LL << 31)) return RNNT_MI355X_UNSUPPORTED_SIZE;
+  return RNNT_MI355X_OK;
+}
+
+int status() { return hipGetLastError() == hipSuccess ? RNNT_MI355X_OK : RNNT_MI355X_LAUNCH_FAILURE; }
+
+}  // namespace
+
+extern "C" {
+
+int rnnt_mi355x_fc_joint_workspace_bytes(int B, int T, int U1, int H, size_t* out_bytes) {
+  if (!out_bytes) return RNNT_MI355X_INVALID_VALUE;
+  const int rc = check_dims(B, T, U1, H);
+  if (rc != RNNT_MI355X_OK) return rc;
+  const int nchunk = (T + kFrames - 1) / kFrames;
+  *out_bytes = sizeof(float) * (size_t)B * nchunk * U1 * H;
+  return RNNT_MI355X_OK;
+}
+
+int rnnt_mi355x_fc_joint_forward(const float* pe, const float* pd, int B, int T, int U1, int H, float* h,
+                                 void* hip_stream) {
+  const int rc = check_dims(B, T, U1, H);
+  if (rc != RNNT_MI355X_OK) return rc;
+  if (!pe || !pd || !h) return RNNT_MI355X_INVALID_VALUE;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const bool vec = H % 4 == 0 && (reinterpret_cast<uintptr_t>(pe) | reinterpret_cast<uintptr_t>(pd) |
+                                  reinterpret_cast<uintptr_t>(h)) % 16 == 0;
+  if (vec) k_fcj_fwd<4><<<B * T, kBlock, 0, st>>>(pe, pd, h, T, U1, H);
+  else k_fcj_fwd<1><<<B * T, kBlock, 0, st>>>(pe, pd, h, T, U1, H);
+  return status();
+}
+
+int rnnt_mi355x_fc_joint_backward(const float* pe, const float* pd, const float* dh, int B, int T, int U1, int H,
+                                  float* dpe, float* dpd, void* workspace, void* hip_stream) {
+  const int rc = check_dims(B, T, U1, H);
+  if (rc != RNNT_MI355X_OK) return rc;
+  if (!pe || !pd || !dh || !dpe || !dpd || !workspace) return RNNT_MI355X_INVALID_VALUE;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const int nchunk = (T + kFrames - 1) / kFrames;
+  const int rows = tile_rows(U1, H);
+  const size_t lds = sizeof(float) * ((size_t)rows * H + 2 * (size_t)kFrames * H);
+  float* partial = static_cast<float*>(workspace);
+  const int nacc = (rows * H + kBlock - 1) / kBlock;  // <= 32
+  const dim3 grid((unsigned)(B * nchunk));
+#define FCJ_BWD(N)                                                                                          \
+  do {                                                                                                      \
+    if (lds > 48 * 1024 &&                                                                                  \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcj_bwd<N>),                                   \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)           \
+      return RNNT_MI355X_LAUNCH_FAILURE;                                                                    \
+    k_fcj_bwd<N><<<grid, kBlock, lds, st>>>(pe, pd, dh, dpe, partial, T, U1, H, rows, nchunk);              \
+  } while (0)
+  if (nacc <= 4) FCJ_BWD(4);
+  else if (nacc <= 8) FCJ_BWD(8);
+  else if (nacc <= 16) FCJ_BWD(16);
+  else FCJ_BWD(32);
+#undef FCJ_BWD
+  const long long total = (long long)B * U1 * H;
+  k_fcj_bwd_reduce<<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, dpd, U1 * H, nchunk, total);
+  return status();
+}
+
+}  // extern "C"

@@ -2175,7 +2175,7 @@ const char* rnnt_mi355x_status_string(int status) {
   switch (status) {
     case RNNT_MI355X_OK: return "ok";
     case RNNT_MI355X_INVALID_VALUE: return "invalid value (null pointer, non-positive size or blank outside [0,V))";
-    case RNNT_MI355X_UNSUPPORTED_SIZE: return "unsupported size (maxU1 > 512 or B*maxT*maxU1 >= 2^31)";
+    case RNNT_MI355X_UNSUPPORTED_SIZE: return "unsupported size (beyond the limits stated in rnnt_mi355x.h)";
     case RNNT_MI355X_LAUNCH_FAILURE: return "HIP launch or copy failure";
     case RNNT_MI355X_BAD_INPUT_DATA: return "device-side validation failed (length or label out of range)";
     default: return "unknown status";

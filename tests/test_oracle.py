@@ -141,3 +141,39 @@ def test_golden_fixtures_match_oracle(golden_dir):
         c, g = orc.rnnt_loss_and_grad(z["logits"], z["labels"], z["in_len"], z["lab_len"], int(z["blank"]), z["grad_scale"])
         np.testing.assert_allclose(c, z["costs"], rtol=1e-12)
         np.testing.assert_allclose(g, z["grad"], atol=1e-12)
+
+
+def test_fc_joint_head_gradients_by_finite_differences():
+    """The FC-joint restatement (concat -> Dense/tanh stack -> lambda v2) against
+    central differences of its own cost, for every input and weight."""
+    rng = np.random.default_rng(77)
+    B, T0, U, He, Hd, H, V = 2, 6, 2, 3, 2, 4, 5
+    yt, yp = rng.standard_normal((B, T0, He)), rng.standard_normal((B, U + 1, Hd))
+    ws = [(rng.standard_normal((He + Hd, H)) * 0.5, rng.standard_normal(H) * 0.1),
+          (rng.standard_normal((H, V)) * 0.5, rng.standard_normal(V) * 0.1)]
+    lab = rng.integers(0, V - 1, (B, U))
+    il, ll = np.array([[6], [5]]), np.array([[2], [1]])
+    costs, dt, dp, dws = orc.fc_joint_loss_and_grads(yt, yp, ws, lab, il, ll, blank_label=4)
+
+    def total():
+        return orc.fc_joint_loss_and_grads(yt, yp, ws, lab, il, ll, blank_label=4)[0].sum()
+
+    def fd(arr, idx, eps=1e-6):
+        old = arr[idx]
+        arr[idx] = old + eps
+        cp = total()
+        arr[idx] = old - eps
+        cm = total()
+        arr[idx] = old
+        return (cp - cm) / (2 * eps)
+
+    for arr, g in ((yt, dt), (yp, dp), (ws[0][0], dws[0][0]), (ws[0][1], dws[0][1]), (ws[1][0], dws[1][0]), (ws[1][1], dws[1][1])):
+        for _ in range(6):
+            idx = tuple(rng.integers(0, n) for n in arr.shape)
+            assert abs(fd(arr, idx) - g[idx]) < 1e-6
+    assert not dt[:, :2].any()  # the two cropped frames (util.py:63)
+    # a single linear layer is the additive joint of rnnt_lambda_func
+    k, b = rng.standard_normal((He + Hd, V)), rng.standard_normal(V)
+    c1 = orc.fc_joint_loss_and_grads(yt, yp, [(k, b)], lab, il, ll, blank_label=4)[0]
+    c2 = orc.rnnt_lambda_func(yt @ k[:He], yp @ k[He:] + b, lab, il, ll, blank_label=4)[0]
+    np.testing.assert_allclose(c1, c2, rtol=1e-12)
