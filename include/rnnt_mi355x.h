@@ -158,6 +158,22 @@ int rnnt_mi355x_fc_joint_forward(const float* pe, const float* pd, int B, int T,
 int rnnt_mi355x_fc_joint_backward(const float* pe, const float* pd, const float* dh, int B, int T, int U1, int H,
                                   float* dpe, float* dpd, void* workspace, void* hip_stream);
 
+/* ---- Dense layers over the joint lattice -------------------------------------
+ * y[M,N] = act(x[M,K] W[K,N] + bias[N]) for a very tall M = B*T*(U+1) and
+ * K, N <= 128: the layers after the first one of KerasModel.get_fc (reference
+ * rnnt/keras_model.py:83-104; TimeDistributed(Dense), tanh on all but the last,
+ * Keras kernel layout [in, out]).  act: 0 linear, 1 tanh.  All float32,
+ * contiguous.  The backward takes the forward output y (used when act == 1)
+ * and the upstream gradient dy[M,N] and writes dx[M,K] (skipped when NULL),
+ * dw[K,N] and db[N] (skipped when dw is NULL; db may be NULL on its own);
+ * dw/db need rnnt_mi355x_dense_workspace_bytes of scratch and are summed in a
+ * fixed order. */
+int rnnt_mi355x_dense_workspace_bytes(long long M, int K, int N, size_t* out_bytes);
+int rnnt_mi355x_dense_forward(const float* x, const float* w, const float* bias, long long M, int K, int N, int act,
+                              float* y, void* hip_stream);
+int rnnt_mi355x_dense_backward(const float* x, const float* w, const float* y, const float* dy, long long M, int K,
+                               int N, int act, float* dx, float* dw, float* db, void* workspace, void* hip_stream);
+
 /* out2[0] = sum_b costs[b], out2[1] = sum of squared gradient elements of the
  * last backward on this workspace (both float64, device memory).  These are
  * the two scalars a data-parallel caller all-reduces: the batch loss of

@@ -8,11 +8,11 @@ Public surface (mirrors the loss call surface of the reference model):
 """
 from .loss import RNNTLoss, rnnt_joint_loss, rnnt_loss, rnnt_loss_grad_  # noqa: F401
 from .lambdas import rnnt_lambda_func, rnnt_lambda_func_v2  # noqa: F401
-from .fc_joint import concatenate_lambda, fc_joint, fc_joint_first_layer, fc_joint_loss  # noqa: F401
+from .fc_joint import concatenate_lambda, fc_joint, fc_joint_first_layer, fc_joint_loss, joint_dense  # noqa: F401
 from .sharding import partition_lpt, shard_batch, allreduce_scalars  # noqa: F401
 
 __all__ = [
     "rnnt_loss", "rnnt_joint_loss", "rnnt_loss_grad_", "RNNTLoss", "rnnt_lambda_func", "rnnt_lambda_func_v2",
-    "concatenate_lambda", "fc_joint", "fc_joint_first_layer", "fc_joint_loss",
+    "concatenate_lambda", "fc_joint", "fc_joint_first_layer", "fc_joint_loss", "joint_dense",
     "partition_lpt", "shard_batch", "allreduce_scalars",
 ]

@@ -23,7 +23,7 @@ FLAG_BAD_LABEL = 2
 
 _lib = None
 
-_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 _META = [_i] * 5  # B, maxT, maxU1, V, blank
 
 _SIGNATURES = {
@@ -41,6 +41,9 @@ _SIGNATURES = {
     "rnnt_mi355x_fc_joint_workspace_bytes": (ctypes.c_int, [_i, _i, _i, _i, ctypes.POINTER(_sz)]),
     "rnnt_mi355x_fc_joint_forward": (ctypes.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rnnt_mi355x_fc_joint_backward": (ctypes.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rnnt_mi355x_dense_workspace_bytes": (ctypes.c_int, [_ll, _i, _i, ctypes.POINTER(_sz)]),
+    "rnnt_mi355x_dense_forward": (ctypes.c_int, [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp]),
+    "rnnt_mi355x_dense_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rnnt_mi355x_reduce_scalars": (ctypes.c_int, [_vp, _i, _vp, _vp, _vp]),
     "rnnt_mi355x_read_status": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
     "rnnt_mi355x_status_string": (ctypes.c_char_p, [_i]),
@@ -88,6 +91,12 @@ def check(rc: int, what: str) -> None:
 def fc_joint_workspace_bytes(B: int, T: int, U1: int, H: int) -> int:
     out = _sz(0)
     check(lib().rnnt_mi355x_fc_joint_workspace_bytes(B, T, U1, H, ctypes.byref(out)), "rnnt_mi355x_fc_joint_workspace_bytes")
+    return int(out.value)
+
+
+def dense_workspace_bytes(M: int, K: int, N: int) -> int:
+    out = _sz(0)
+    check(lib().rnnt_mi355x_dense_workspace_bytes(M, K, N, ctypes.byref(out)), "rnnt_mi355x_dense_workspace_bytes")
     return int(out.value)
 
 

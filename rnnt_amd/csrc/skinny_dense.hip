@@ -1,0 +1,330 @@
+// Dense layers over the joint lattice for MI355X (gfx950): y[M,N] = act(x[M,K] W[K,N] + b) with a very tall
+// M = B*T*(U+1) and small K, N <= 128 -- the layers after the first one of the reference's fully-connected
+// joint (KerasModel.get_fc, reference rnnt/keras_model.py:83-104: TimeDistributed(Dense) with tanh on all but
+// the last layer; the sample model has K = 100, N = 62).  A general GEMM library tiles such a product for a
+// large N and runs it at a few percent of what the memory system allows; here the whole weight matrix sits in
+// LDS, a wavefront streams 32 rows of x at a time through v_mfma_f32_32x32x2_f32 and the kernels are bound by
+// reading x and writing y once.
+//
+//   k_dense_fwd   y = act(x W + b)                       (also the data gradient: dx = (dy * act') W^T)
+//   k_dense_wgrad partial dW, db per block: X^T (dy * act') contracted over a chunk of rows; a row of ones
+//                 appended to X^T makes the bias gradient one more row of the same product
+//   k_dense_wgrad_reduce   sums the partials in block order (no atomics: bit-reproducible)
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/rnnt_mi355x.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxDim = 128;
+constexpr int kWgradBlocks = 1024;
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int mm_row(int r, int lane) { return 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); }
+
+// 4 consecutive floats p[0..3] of a row, zero where col + i >= ncol or !row_ok.  VEC = widest aligned access.
+template <int VEC>
+__device__ __forceinline__ void load4(const float* p, int col, int ncol, bool row_ok, float (&v)[4]) {
+  if (VEC == 4 && row_ok && col + 4 <= ncol) {
+    const f4v t = *reinterpret_cast<const f4v*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  } else if (VEC == 2 && row_ok && col + 4 <= ncol) {
+    const f2v t0 = *reinterpret_cast<const f2v*>(p), t1 = *reinterpret_cast<const f2v*>(p + 2);
+    v[0] = t0[0]; v[1] = t0[1]; v[2] = t1[0]; v[3] = t1[1];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (row_ok && col + i < ncol) ? p[i] : 0.f;
+  }
+}
+
+// NT consecutive floats at p (columns col..col+NT-1 of a row of ncol), zero past the end / when !row_ok
+template <int NT>
+__device__ __forceinline__ void loadn(const float* p, int col, int ncol, bool row_ok, bool vec_ok, float (&v)[NT]) {
+  if (NT == 4 && vec_ok && row_ok && col + 4 <= ncol) {
+    const f4v t = *reinterpret_cast<const f4v*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  } else if (NT == 2 && vec_ok && row_ok && col + 2 <= ncol) {
+    const f2v t = *reinterpret_cast<const f2v*>(p);
+    v[0] = t[0]; v[1] = t[1];
+  } else {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) v[i] = (row_ok && col + i < ncol) ? p[i] : 0.f;
+  }
+}
+
+// y[m, :] = act(a[m, :] W + b), a = x or, with DACT (data gradient through a tanh layer), a = g * (1 - z^2) with
+// g the upstream gradient and z the layer's forward output.  W arrives as wt[k][n] = W[k][n] (TRANS = false) or
+// W[n][k] (TRANS = true: the data gradient multiplies by W^T).  Kd = contraction length, Nd = output columns.
+// LDS: W zero-padded to [Kp][Np + 4].  Lane l of MFMA tile j owns output column NT*(l%32) + j.
+template <int NT, int AVEC, bool DACT, bool TRANS>
+__global__ __launch_bounds__(kBlock) void k_dense_fwd(const float* __restrict__ a, const float* __restrict__ z,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ y, long long M, int Kd, int Nd, int act,
+                                                      bool yvec_ok) {
+  extern __shared__ float wl[];
+  constexpr int Np = 32 * NT, pitch = Np + 4;
+  const int Kp = (Kd + 7) & ~7;
+  for (int i = threadIdx.x; i < Kp * Np; i += kBlock) {
+    const int k = i / Np, n = i - k * Np;
+    float v = 0.f;
+    if (k < Kd && n < Nd) v = TRANS ? w[(size_t)n * Kd + k] : w[(size_t)k * Nd + n];
+    wl[k * pitch + n] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5;
+  const int col = NT * l32;
+  float bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bv[j] = (bias && col + j < Nd) ? bias[col + j] : 0.f;
+  // Plain loop, many resident waves: keeping a whole 32 x K slab (or two) of a in registers ahead of the MFMAs
+  // measured 0-35 % slower (fewer waves per SIMD); the limiter is the 16-byte-per-row access to a.
+  const long long tiles = (M + 31) / 32;
+  const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  for (long long tile = wave0; tile < tiles; tile += nwaves) {
+    const long long m0 = tile * 32;
+    const long long mrow = m0 + l32;
+    const bool row_ok = mrow < M;
+    const float* ap = a + (size_t)(row_ok ? mrow : 0) * Kd + 4 * h;
+    const float* zp = DACT ? z + (size_t)(row_ok ? mrow : 0) * Kd + 4 * h : nullptr;
+    f16v acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int k0 = 0; k0 < Kp; k0 += 8) {
+      float av[4];
+      load4<AVEC>(ap + k0, k0 + 4 * h, Kd, row_ok, av);
+      if (DACT) {
+        float zv[4];
+        load4<AVEC>(zp + k0, k0 + 4 * h, Kd, row_ok, zv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] *= 1.f - zv[i] * zv[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* wr = wl + (k0 + 4 * h + i) * pitch + col;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], wr[j], acc[j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long m = m0 + mm_row(r, lane);
+      if (m >= M) continue;
+      float o[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float v = acc[j][r] + bv[j];
+        if (act == 1) {
+          const float e = __builtin_amdgcn_exp2f(v * 2.885390081777927f);
+          v = 1.f - 2.f / (e + 1.f);
+        }
+        o[j] = v;
+      }
+      float* yp = y + (size_t)m * Nd + col;
+      if (NT == 4 && yvec_ok && col + 4 <= Nd) {
+        const f4v t = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f4v*>(yp) = t;
+      } else if (NT == 2 && yvec_ok && col + 2 <= Nd) {
+        const f2v t = {o[0], o[1]};
+        *reinterpret_cast<f2v*>(yp) = t;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          if (col + j < Nd) yp[j] = o[j];
+      }
+    }
+  }
+}
+
+// Partial weight gradient of one block over its chunk of rows: P[k][n] = sum_m X(m,k) G(m,n) for k < K and
+// P[K][n] = sum_m G(m,n) (bias), G = dy or, with DACT, dy * (1 - y^2).  Wave w of the block owns rows
+// 32w..32w+31 of P (a wave may own none, or, for K = 128, two).  partial: [gridDim.x][Kr][Np], Kr = 32 * KT.
+template <int NT, bool DACT>
+__global__ __launch_bounds__(kBlock) void k_dense_wgrad(const float* __restrict__ x, const float* __restrict__ yout,
+                                                        const float* __restrict__ dy, float* __restrict__ partial,
+                                                        long long M, int K, int N, int KT, long long rows_per_block,
+                                                        bool gvec_ok) {
+  constexpr int Np = 32 * NT;
+  const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+  const int col = NT * l32;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  for (int kt = wv; kt < KT; kt += 4) {  // KT <= 4 except for K = 128 (129 rows with the bias row)
+    const int kx = 32 * kt + l32;  // row of P (column of x) this lane feeds; kx == K is the row of ones
+    f16v acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (long long m0 = r0; m0 < r1; m0 += 8) {  // (alternating operand register sets measured slower here too)
+      float av[4], gv[4][NT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long m = m0 + 4 * h + i;
+        const bool ok = m < r1;
+        av[i] = !ok ? 0.f : kx < K ? x[(size_t)m * K + kx] : kx == K ? 1.f : 0.f;
+        loadn<NT>(dy + (size_t)(ok ? m : 0) * N + col, col, N, ok, gvec_ok, gv[i]);
+        if (DACT) {
+          float yv[NT];
+          loadn<NT>(yout + (size_t)(ok ? m : 0) * N + col, col, N, ok, gvec_ok, yv);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) gv[i][j] *= 1.f - yv[j] * yv[j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], gv[i][j], acc[j], 0, 0, 0);
+    }
+    float* out = partial + (size_t)blockIdx.x * (32 * KT) * Np;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* o = out + (size_t)(32 * kt + mm_row(r, lane)) * Np + col;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) o[j] = acc[j][r];
+    }
+  }
+}
+
+// dw[k][n] = sum over blocks of partial[blk][k][n] (k < K), db[n] = the same for row K.  16 lanes per output
+// element: lane q adds the partials of blocks q, q+16, ... in order, then the 16 sums are added pairwise in a
+// fixed pattern -- the result does not depend on scheduling.
+__global__ __launch_bounds__(kBlock) void k_dense_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
+                                                               float* __restrict__ db, int K, int N, int Kr, int Np,
+                                                               int nblocks) {
+  const int i = (blockIdx.x * kBlock + threadIdx.x) >> 4, q = threadIdx.x & 15;
+  const bool in_range = i < (K + 1) * N;
+  const int k = in_range ? i / N : 0, n = in_range ? i - k * N : 0;
+  const float* p = partial + (size_t)k * Np + n;
+  float s = 0.f;
+  if (in_range)
+    for (int b = q; b < nblocks; b += 16) s += p[(size_t)b * Kr * Np];
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  s += __shfl_xor(s, 8, 64);
+  if (in_range && q == 0) {
+    if (k < K) dw[(size_t)k * N + n] = s;
+    else if (db) db[n] = s;
+  }
+}
+
+int check_dims(long long M, int K, int N, int act) {
+  if (M < 1 || K < 1 || N < 1 || (act != 0 && act != 1)) return RNNT_MI355X_INVALID_VALUE;
+  if (K > kMaxDim || N > kMaxDim || M >= (1LL << 40)) return RNNT_MI355X_UNSUPPORTED_SIZE;
+  return RNNT_MI355X_OK;
+}
+int status() { return hipGetLastError() == hipSuccess ? RNNT_MI355X_OK : RNNT_MI355X_LAUNCH_FAILURE; }
+inline int nt_for(int n) { return n <= 32 ? 1 : n <= 64 ? 2 : 4; }
+inline int avec_for(const void* p, int ncol) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  return (ncol % 4 == 0 && a % 16 == 0) ? 4 : (ncol % 2 == 0 && a % 8 == 0) ? 2 : 1;
+}
+inline bool nvec_ok(const void* p, int ncol, int nt) {
+  return nt == 1 || (ncol % nt == 0 && reinterpret_cast<uintptr_t>(p) % (sizeof(float) * nt) == 0);
+}
+inline unsigned fwd_grid(long long M) {
+  const long long blocks = ((M + 31) / 32 + 3) / 4;
+  return (unsigned)(blocks < 2048 ? blocks : 2048);  // persistent: 8 blocks per CU at most
+}
+inline int wgrad_blocks(long long M) {
+  const long long b = (M + 255) / 256;
+  return (int)(b < kWgradBlocks ? b : kWgradBlocks);
+}
+
+// y = act(a W (+b)) or the data gradient; Kd/Nd in the kernel's own orientation
+template <bool DACT, bool TRANS>
+int launch_fwd(const float* a, const float* z, const float* w, const float* bias, float* y, long long M, int Kd, int Nd,
+               int act, hipStream_t st) {
+  const int nt = nt_for(Nd);
+  int avec = avec_for(a, Kd);
+  if (DACT) {
+    const int zvec = avec_for(z, Kd);
+    avec = avec < zvec ? avec : zvec;
+  }
+  const bool yv = nvec_ok(y, Nd, nt);
+  const size_t lds = sizeof(float) * (size_t)((Kd + 7) & ~7) * (32 * nt + 4);
+  const unsigned grid = fwd_grid(M);
+#define DENSE_FWD(NT, AV)                                                                                        \
+  do {                                                                                                           \
+    if (lds > 48 * 1024 &&                                                                                       \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_fwd<NT, AV, DACT, TRANS>),                    \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
+      return RNNT_MI355X_LAUNCH_FAILURE;                                                                         \
+    k_dense_fwd<NT, AV, DACT, TRANS><<<grid, kBlock, lds, st>>>(a, z, w, bias, y, M, Kd, Nd, act, yv);           \
+  } while (0)
+#define DENSE_FWD_AV(NT)              \
+  do {                                \
+    if (avec == 4) DENSE_FWD(NT, 4);  \
+    else if (avec == 2) DENSE_FWD(NT, 2); \
+    else DENSE_FWD(NT, 1);            \
+  } while (0)
+  if (nt == 1) DENSE_FWD_AV(1);
+  else if (nt == 2) DENSE_FWD_AV(2);
+  else DENSE_FWD_AV(4);
+#undef DENSE_FWD_AV
+#undef DENSE_FWD
+  return status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int rnnt_mi355x_dense_workspace_bytes(long long M, int K, int N, size_t* out_bytes) {
+  if (!out_bytes) return RNNT_MI355X_INVALID_VALUE;
+  const int rc = check_dims(M, K, N, 0);
+  if (rc != RNNT_MI355X_OK) return rc;
+  const int KT = (K + 1 + 31) / 32;
+  *out_bytes = sizeof(float) * (size_t)wgrad_blocks(M) * (32 * KT) * (32 * nt_for(N));
+  return RNNT_MI355X_OK;
+}
+
+int rnnt_mi355x_dense_forward(const float* x, const float* w, const float* bias, long long M, int K, int N, int act,
+                              float* y, void* hip_stream) {
+  const int rc = check_dims(M, K, N, act);
+  if (rc != RNNT_MI355X_OK) return rc;
+  if (!x || !w || !y) return RNNT_MI355X_INVALID_VALUE;
+  return launch_fwd<false, false>(x, nullptr, w, bias, y, M, K, N, act, static_cast<hipStream_t>(hip_stream));
+}
+
+int rnnt_mi355x_dense_backward(const float* x, const float* w, const float* y, const float* dy, long long M, int K,
+                               int N, int act, float* dx, float* dw, float* db, void* workspace, void* hip_stream) {
+  const int rc = check_dims(M, K, N, act);
+  if (rc != RNNT_MI355X_OK) return rc;
+  if (!x || !w || !dy || (act == 1 && !y) || (dw && !workspace) || (db && !dw)) return RNNT_MI355X_INVALID_VALUE;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (dx) {  // dx[M,K] = (dy * act') W^T: the forward kernel with the roles of K and N exchanged
+    const int r = act == 1 ? launch_fwd<true, true>(dy, y, w, nullptr, dx, M, N, K, 0, st)
+                           : launch_fwd<false, true>(dy, nullptr, w, nullptr, dx, M, N, K, 0, st);
+    if (r != RNNT_MI355X_OK) return r;
+  }
+  if (dw) {
+    const int nt = nt_for(N), KT = (K + 1 + 31) / 32, nb = wgrad_blocks(M);
+    long long rows = (M + nb - 1) / nb;
+    rows = (rows + 7) & ~7LL;
+    const bool gv = nvec_ok(dy, N, nt) && (act == 0 || nvec_ok(y, N, nt));
+    float* partial = static_cast<float*>(workspace);
+#define DENSE_WGRAD(NT)                                                                                          \
+  do {                                                                                                           \
+    if (act == 1) k_dense_wgrad<NT, true><<<nb, kBlock, 0, st>>>(x, y, dy, partial, M, K, N, KT, rows, gv);       \
+    else k_dense_wgrad<NT, false><<<nb, kBlock, 0, st>>>(x, y, dy, partial, M, K, N, KT, rows, gv);               \
+  } while (0)
+    if (nt == 1) DENSE_WGRAD(1);
+    else if (nt == 2) DENSE_WGRAD(2);
+    else DENSE_WGRAD(4);
+#undef DENSE_WGRAD
+    const int total = (K + 1) * N * 16;
+    k_dense_wgrad_reduce<<<(total + kBlock - 1) / kBlock, kBlock, 0, st>>>(partial, dw, db, K, N, 32 * KT, 32 * nt, nb);
+  }
+  return status();
+}
+
+}  // extern "C"

@@ -13,7 +13,9 @@ in the concatenation, so here it is computed as two small matrix products
 broadcasts, adds and applies tanh; backwards one HIP pass over the upstream
 gradient gives both reduced gradients.  With a single layer the joint is an
 additive one and goes straight to the fused additive-joint loss, so not even
-[B,T,U+1,V] is formed.  Dropout (training-time noise, keras_model.py:102-103)
+[B,T,U+1,V] is formed.  The following layers multiply a [B*T*(U+1), hidden]
+matrix by a small kernel: up to 128 x 128 they run on hand-written tall-skinny
+MFMA kernels (weights resident in LDS), beyond that on the library GEMM.  Dropout (training-time noise, keras_model.py:102-103)
 is not part of these functions.
 """
 from __future__ import annotations
@@ -72,6 +74,59 @@ def fc_joint_first_layer(pe, pd):
     return _FirstLayerFn.apply(pe.float().contiguous(), pd.float().contiguous())
 
 
+DENSE_MAX_DIM = 128  # rnnt_mi355x_dense_*: both layer widths at most this, else the library GEMM
+
+
+class _DenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, bias, act):
+        K, N = kernel.shape
+        M = x.numel() // K
+        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().rnnt_mi355x_dense_forward(_ptr(x), _ptr(kernel), _ptr(bias), M, K, N, act, _ptr(y),
+                                                     _stream_ptr(x.device))
+        _lib.check(rc, "rnnt_mi355x_dense_forward")
+        ctx.save_for_backward(x, kernel, y if act == 1 else None)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, kernel, y = ctx.saved_tensors
+        K, N = kernel.shape
+        M = x.numel() // K
+        dy = dy.contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        dw, db = torch.empty_like(kernel), torch.empty(N, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            ws = torch.empty(_lib.dense_workspace_bytes(M, K, N), dtype=torch.uint8, device=x.device)
+            rc = _lib.lib().rnnt_mi355x_dense_backward(_ptr(x), _ptr(kernel), _ptr(y), _ptr(dy), M, K, N, ctx.act,
+                                                      _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), _stream_ptr(x.device))
+        _lib.check(rc, "rnnt_mi355x_dense_backward")
+        return dx, dw, db, None
+
+
+def joint_dense(x, kernel, bias, activation="linear"):
+    """One TimeDistributed(Dense) of get_fc (keras_model.py:88-101) over x[..., K]:
+    activation(x @ kernel[K,N] + bias[N]), "linear" or "tanh".  Widths up to
+    DENSE_MAX_DIM run on the hand-written tall-skinny kernels; wider layers go
+    to the library GEMM, which is efficient there."""
+    if activation not in ("linear", "tanh"):
+        raise ValueError("joint_dense: activation must be 'linear' or 'tanh'")
+    K, N = kernel.shape
+    if x.shape[-1] != K:
+        raise ValueError(f"joint_dense: x has {x.shape[-1]} features, kernel expects {K}")
+    if K > DENSE_MAX_DIM or N > DENSE_MAX_DIM:
+        z = torch.matmul(x, kernel) + bias
+        return torch.tanh(z) if activation == "tanh" else z
+    if x.device.type != "cuda":
+        raise ValueError("joint_dense: tensors must live on an MI355X device (there is no CPU path)")
+    return _DenseFn.apply(x.float().contiguous(), kernel.float().contiguous(), bias.float().contiguous(),
+                          1 if activation == "tanh" else 0)
+
+
 def fc_joint(y_trans, y_pred, weights):
     """concatenate_lambda + get_fc without the tiled tensor.
 
@@ -91,9 +146,9 @@ def fc_joint(y_trans, y_pred, weights):
         return pe.unsqueeze(2) + pd.unsqueeze(1)
     h = fc_joint_first_layer(pe, pd)
     for k, b in weights[1:-1]:
-        h = torch.tanh(torch.matmul(h, k) + b)
+        h = joint_dense(h, k, b, "tanh")
     k, b = weights[-1]
-    return torch.matmul(h, k) + b
+    return joint_dense(h, k, b, "linear")
 
 
 def fc_joint_loss(y_trans, y_pred, weights, labels, input_length, label_length, blank_label=REFERENCE_BLANK_LABEL):

@@ -119,3 +119,51 @@ def test_fc_joint_equals_dense_stack_on_the_tiled_tensor():
     out = rnnt_amd.fc_joint(yt, yp, ws)
     assert out.shape == (B, T, U1, 5)
     assert (out - x).abs().max().item() < 1e-5
+
+
+# M, K, N: the reference sample's last layer (100 -> 62), widths that are not multiples of anything, the limits,
+# a single row, many row tiles with a ragged tail
+DENSE_SHAPES = [(1000, 100, 62), (77, 7, 5), (4097, 128, 128), (1, 3, 2), (333, 33, 100), (50000, 100, 62), (260, 64, 32)]
+
+
+@pytest.mark.parametrize("M,K,N", DENSE_SHAPES)
+@pytest.mark.parametrize("act", ["linear", "tanh"])
+def test_joint_dense_matches_float64(M, K, N, act):
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    k = rng.uniform(-0.3, 0.3, (K, N)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, N).astype(np.float32)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    z = x.astype(np.float64) @ k.astype(np.float64) + b
+    y = np.tanh(z) if act == "tanh" else z
+    g = dy.astype(np.float64) * ((1 - y ** 2) if act == "tanh" else 1.0)
+    tx = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    tk = torch.from_numpy(k).to(DEV).requires_grad_(True)
+    tb = torch.from_numpy(b).to(DEV).requires_grad_(True)
+    out = rnnt_amd.joint_dense(tx, tk, tb, act)
+    out.backward(torch.from_numpy(dy).to(DEV))
+    assert np.abs(out.detach().cpu().numpy() - y).max() < 1e-5
+    assert np.abs(tx.grad.cpu().numpy() - g @ k.astype(np.float64).T).max() < 1e-5 * max(1, N) ** 0.5 * 4
+    scale = max(1.0, np.sqrt(M))
+    assert np.abs(tk.grad.cpu().numpy() - x.astype(np.float64).T @ g).max() < 2e-5 * scale
+    assert np.abs(tb.grad.cpu().numpy() - g.sum(0)).max() < 2e-5 * scale
+    # bit-reproducible
+    tx.grad = tk.grad = tb.grad = None
+    out2 = rnnt_amd.joint_dense(tx, tk, tb, act)
+    gk = torch.autograd.grad(out2, tk, torch.from_numpy(dy).to(DEV))[0]
+    out3 = rnnt_amd.joint_dense(tx, tk, tb, act)
+    gk2 = torch.autograd.grad(out3, tk, torch.from_numpy(dy).to(DEV))[0]
+    assert torch.equal(gk, gk2) and torch.equal(out2, out3)
+
+
+def test_joint_dense_wide_layers_use_the_library_and_bad_arguments_raise():
+    x = torch.randn(10, 200, device=DEV)
+    k, b = torch.randn(200, 30, device=DEV), torch.zeros(30, device=DEV)
+    assert (rnnt_amd.joint_dense(x, k, b) - (x @ k + b)).abs().max().item() < 1e-4
+    with pytest.raises(ValueError):
+        rnnt_amd.joint_dense(x, torch.randn(100, 30, device=DEV), b)
+    with pytest.raises(ValueError):
+        rnnt_amd.joint_dense(x, k, b, "relu")
+    L = _lib.lib()
+    assert L.rnnt_mi355x_dense_forward(_p(x), _p(k), None, 10, 200, 30, 0, _p(x), None) == 2   # K beyond the limit
+    assert L.rnnt_mi355x_dense_forward(_p(x), _p(k), None, 10, 100, 30, 2, _p(x), None) == 1   # unknown activation
