@@ -174,6 +174,19 @@ int rnnt_mi355x_dense_forward(const float* x, const float* w, const float* bias,
 int rnnt_mi355x_dense_backward(const float* x, const float* w, const float* y, const float* dy, long long M, int K,
                                int N, int act, float* dx, float* dw, float* db, void* workspace, void* hip_stream);
 
+/* ---- decoder step ---------------------------------------------------------
+ * out[n, :] = log_softmax(f[f_index[n], :] + g[g_index[n], :]) over V, n < n_rows:
+ * the joint + Util.softmax(out, is_log=True) the reference's beam search
+ * evaluates one vector at a time (reference rnnt/rnnt_decoder.py:156-158,
+ * 170-171, 200-202; rnnt/base/util.py:295-309), batched over any number of
+ * (encoder frame, hypothesis) pairs.  f: [f_rows,V], g: [g_rows,V] or NULL (then
+ * out = log_softmax(f rows)); the index arrays are int32 [n_rows] or NULL (= row
+ * n).  An index outside its tensor sets *bad_index_flag (device int32, zeroed by
+ * the caller) to 1 and row 0 is used instead.  out: [n_rows,V]. */
+int rnnt_mi355x_joint_log_softmax(const float* f, int f_rows, const float* g, int g_rows, const int32_t* f_index,
+                                  const int32_t* g_index, int n_rows, int V, float* out, int32_t* bad_index_flag,
+                                  void* hip_stream);
+
 /* out2[0] = sum_b costs[b], out2[1] = sum of squared gradient elements of the
  * last backward on this workspace (both float64, device memory).  These are
  * the two scalars a data-parallel caller all-reduces: the batch loss of

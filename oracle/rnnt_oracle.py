@@ -264,6 +264,28 @@ def fc_joint_loss_and_grads(y_trans, y_pred, weights, labels, input_length, labe
     return costs, d[..., :He].sum(axis=2), d[..., He:].sum(axis=1), dws
 
 
+def util_softmax(value, is_log=False, axis=None):
+    """``Util.softmax`` (reference util.py:295-309) statement by statement, in
+    float64.  With ``axis=0`` the reference recurses on every element of
+    ``value`` WITHOUT ``is_log`` (util.py:299-301): rows of a matrix get a plain
+    softmax each, and the elements of a vector -- scalars -- each become 1.0."""
+    if axis is not None:
+        assert axis == 0  # util.py:298
+        return [util_softmax(elem) for elem in np.asarray(value, dtype=np.float64)]  # util.py:299-301
+    value = np.asarray(value, dtype=np.float64)
+    e_x = np.exp(value - np.max(value))  # util.py:303
+    if is_log:
+        with np.errstate(divide="ignore"):
+            return np.log(e_x) - np.log(e_x.sum())  # util.py:305
+    return e_x / e_x.sum()  # util.py:307
+
+
+def decoder_step_logp(encoder_output_t, pred):
+    """The decoder's inner step (reference rnnt_decoder.py:156-158, 200-202):
+    out = pred + encoder_output_t; logp = Util.softmax(out, is_log=True)."""
+    return util_softmax(np.asarray(pred, np.float64) + np.asarray(encoder_output_t, np.float64), is_log=True)
+
+
 # ---------------------------------------------------------------------------
 # Independent second opinions used to pin the oracle itself.
 # ---------------------------------------------------------------------------

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "rnnt_mi355x_dense_workspace_bytes": (ctypes.c_int, [_ll, _i, _i, ctypes.POINTER(_sz)]),
     "rnnt_mi355x_dense_forward": (ctypes.c_int, [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp]),
     "rnnt_mi355x_dense_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rnnt_mi355x_joint_log_softmax": (ctypes.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "rnnt_mi355x_reduce_scalars": (ctypes.c_int, [_vp, _i, _vp, _vp, _vp]),
     "rnnt_mi355x_read_status": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
     "rnnt_mi355x_status_string": (ctypes.c_char_p, [_i]),

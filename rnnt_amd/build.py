@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = [os.path.join(CSRC, "rnnt_mi355x.hip"), os.path.join(CSRC, "fc_joint.hip"),
-           os.path.join(CSRC, "skinny_dense.hip")]
+           os.path.join(CSRC, "skinny_dense.hip"), os.path.join(CSRC, "decode_step.hip")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rnnt_mi355x.h")
 LIB = os.path.join(CSRC, "librnnt_mi355x.so")
 

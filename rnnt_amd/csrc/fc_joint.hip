@@ -34,7 +34,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // tanh(x) = 1 - 2 / (2^(2x log2 e) + 1); exact limits at +-inf, relative error ~2e-7
 __device__ __forceinline__ float tanh_fast(float x) {
   const float e = __builtin_amdgcn_exp2f(x * kTwoLog2e);
-  return 1.f - 2.f / (e + 1.f);
+  return __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
 }
 
 // rows of pd (label positions) per LDS tile, and tiles per utterance

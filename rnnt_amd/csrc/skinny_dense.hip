@@ -97,20 +97,35 @@ __global__ __launch_bounds__(kBlock) void k_dense_fwd(const float* __restrict__ 
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    for (int k0 = 0; k0 < Kp; k0 += 8) {
-      float av[4];
-      load4<AVEC>(ap + k0, k0 + 4 * h, Kd, row_ok, av);
-      if (DACT) {
-        float zv[4];
-        load4<AVEC>(zp + k0, k0 + 4 * h, Kd, row_ok, zv);
+    // 32 columns (one 128-byte line of every row) per round: the four 16-byte pieces a lane takes from its row's
+    // line are requested back to back, so the line is fetched once instead of once per piece
+    for (int k0 = 0; k0 < Kp; k0 += 32) {
+      float av[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) av[i] *= 1.f - zv[i] * zv[i];
+      for (int q = 0; q < 4; ++q) {
+        const int kq = k0 + 8 * q;
+        if (kq < Kp) {  // uniform
+          load4<AVEC>(ap + kq, kq + 4 * h, Kd, row_ok, av[q]);
+          if (DACT) {
+            float zv[4];
+            load4<AVEC>(zp + kq, kq + 4 * h, Kd, row_ok, zv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[q][i] *= 1.f - zv[i] * zv[i];
+          }
+        }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* wr = wl + (k0 + 4 * h + i) * pitch + col;
+      for (int q = 0; q < 4; ++q) {
+        const int kq = k0 + 8 * q;
+        if (kq < Kp) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], wr[j], acc[j], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) {
+            const float* wr = wl + (kq + 4 * h + i) * pitch + col;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][i], wr[j], acc[j], 0, 0, 0);
+          }
+        }
       }
     }
 #pragma unroll
@@ -123,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_fwd(const float* __restrict__ 
         float v = acc[j][r] + bv[j];
         if (act == 1) {
           const float e = __builtin_amdgcn_exp2f(v * 2.885390081777927f);
-          v = 1.f - 2.f / (e + 1.f);
+          v = __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
         }
         o[j] = v;
       }

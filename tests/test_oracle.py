@@ -177,3 +177,19 @@ def test_fc_joint_head_gradients_by_finite_differences():
     c1 = orc.fc_joint_loss_and_grads(yt, yp, [(k, b)], lab, il, ll, blank_label=4)[0]
     c2 = orc.rnnt_lambda_func(yt @ k[:He], yp @ k[He:] + b, lab, il, ll, blank_label=4)[0]
     np.testing.assert_allclose(c1, c2, rtol=1e-12)
+
+
+def test_util_softmax_restatement():
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(62) * 3
+    p = orc.util_softmax(x)
+    assert abs(p.sum() - 1) < 1e-12 and np.all(p > 0)
+    np.testing.assert_allclose(orc.util_softmax(x, is_log=True), np.log(p), atol=1e-12)
+    np.testing.assert_allclose(orc.util_softmax(x, is_log=True), orc.log_softmax(x[None])[0], atol=1e-12)
+    # the axis=0 branch drops is_log and works element by element (util.py:297-301)
+    assert orc.util_softmax(x, is_log=True, axis=0) == [1.0] * 62
+    m = rng.standard_normal((3, 5))
+    rows = orc.util_softmax(m, is_log=True, axis=0)
+    for r, row in zip(rows, m):
+        np.testing.assert_allclose(r, np.exp(row) / np.exp(row).sum(), atol=1e-12)
+    np.testing.assert_allclose(orc.decoder_step_logp(x, x[::-1]), orc.log_softmax((x + x[::-1])[None])[0], atol=1e-12)
