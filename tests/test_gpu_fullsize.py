@@ -142,3 +142,40 @@ def test_pruned_rows_are_truly_negligible():
     assert zero_rows.mean() > 0.2                       # the prune does fire at this size
     assert np.abs(go[zero_rows]).max() < 1e-11
     assert np.abs(g - go).max() < 2e-5
+
+
+@pytest.mark.parametrize("B,T,U,V,blank", [(32, 500, 100, 62, 39), (16, 400, 100, 1024, 1023)])
+def test_fused_joint_full_size_equals_materialised_path(B, T, U, V, blank):
+    """BASELINE shapes 2 and 3 (a quarter of config 3's batch): the additive-joint path (matrix-core
+    contractions, nothing of size T*U*V) against broadcast add + the materialised loss + reductions."""
+    import rnnt_amd
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + V)
+    f = torch.empty((B, T, V), device=dev).normal_(generator=g)
+    gg = torch.empty((B, U + 1, V), device=dev).normal_(generator=g)
+    lab = torch.randint(0, V - 1, (B, U), generator=g, device=dev, dtype=torch.int32)
+    lab = lab + (lab >= blank).to(torch.int32)
+    il = torch.randint(T // 2, T + 1, (B,), generator=g, device=dev, dtype=torch.int32)
+    ll = torch.randint(U // 2, U + 1, (B,), generator=g, device=dev, dtype=torch.int32)
+    il[0], ll[0] = T, U
+    f1, g1 = f.clone().requires_grad_(True), gg.clone().requires_grad_(True)
+    c1 = rnnt_amd.rnnt_joint_loss(f1, g1, lab, il, ll, blank)
+    c1.mean().backward()
+    f2, g2 = f.clone().requires_grad_(True), gg.clone().requires_grad_(True)
+    c2 = rnnt_amd.rnnt_loss(f2.unsqueeze(2) + g2.unsqueeze(1), lab, il, ll, blank, inplace=True)
+    c2.mean().backward()
+    torch.testing.assert_close(c1, c2, rtol=COST_RTOL, atol=0)
+    assert (f1.grad - f2.grad).abs().max().item() < GRAD_ATOL
+    assert (g1.grad - g2.grad).abs().max().item() < GRAD_ATOL
+    # frames / label positions beyond an utterance's lengths get exact zeros
+    for b in range(B):
+        assert not f1.grad[b, int(il[b]):].any() and not g1.grad[b, int(ll[b]) + 1:].any()
+    # exact parity of one utterance with the float64 oracle
+    b = 1
+    Tb, Ub = int(il[b]), int(ll[b])
+    joint = f[b, :Tb, None, :].double().cpu().numpy() + gg[b, None, :Ub + 1, :].double().cpu().numpy()
+    co, go = orc.rnnt_loss_and_grad(joint[None], lab[b:b + 1, :].cpu().numpy(), [Tb], [Ub], blank, [1.0 / B])
+    np.testing.assert_allclose(c1[b].item(), co[0], rtol=COST_RTOL)
+    assert np.abs(f1.grad[b, :Tb].cpu().numpy() - go[0].sum(1)).max() < GRAD_ATOL
+    assert np.abs(g1.grad[b, :Ub + 1].cpu().numpy() - go[0].sum(0)).max() < GRAD_ATOL

@@ -299,3 +299,44 @@ def test_lambda_func_fused_and_unfused_agree():
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=COST_RTOL)
     assert np.abs(res[0][1] - res[1][1]).max() < GRAD_ATOL and np.abs(res[0][2] - res[1][2]).max() < GRAD_ATOL
     assert not res[0][1][:, :2].any()
+
+
+def test_entry_points_can_be_captured_in_a_hip_graph():
+    """No entry point allocates, frees or synchronises, so a whole loss + gradient step can be recorded
+    once into a HIP graph and replayed (what a launch-bound small-batch training loop wants)."""
+    import ctypes
+    from rnnt_amd import _lib
+    x, lab, il, ll = make_batch(4, 30, 12, 62, 39, seed=21)
+    co, go = orc.rnnt_loss_and_grad(x, lab, il, ll, 39, np.full(4, 0.25))
+    dev = torch.device(DEV)
+    master = torch.from_numpy(x).to(dev)
+    buf = master.clone()
+    t_lab, t_il, t_ll = (torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev) for a in (lab, il, ll))
+    gs = torch.full((4,), 0.25, device=dev)
+    costs = torch.zeros(4, device=dev)
+    scal = torch.zeros(2, dtype=torch.float64, device=dev)
+    ws = torch.empty(_lib.workspace_bytes(4, 30, 13), dtype=torch.uint8, device=dev)
+    L = _lib.lib()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def step(stream):
+        sp = ctypes.c_void_p(stream.cuda_stream)
+        buf.copy_(master)
+        assert L.rnnt_mi355x_loss_grad(p(buf), p(t_lab), p(t_il), p(t_ll), 4, 30, 13, 62, 39, p(gs), p(costs), p(ws), sp) == 0
+        assert L.rnnt_mi355x_reduce_scalars(p(costs), 4, p(ws), p(scal), sp) == 0
+
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        step(side)                                  # warm-up outside the capture
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step(torch.cuda.current_stream(dev))
+    for _ in range(3):
+        costs.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(costs.cpu().numpy(), co, rtol=COST_RTOL)
+    assert np.abs(buf.cpu().numpy() - go).max() < GRAD_ATOL
+    np.testing.assert_allclose(scal.cpu().numpy()[0], co.sum(), rtol=COST_RTOL)
