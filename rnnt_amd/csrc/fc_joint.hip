@@ -77,7 +77,9 @@ __global__ __launch_bounds__(kBlock) void k_fcj_fwd(const float* __restrict__ pe
 // chunk: d = dh * (1 - tanh^2(pe + pd)) goes to an LDS tile [rows][H]; the threads keep the sums over the
 // chunk's frames of their own tile elements in registers (-> partial[b][chunk][u][h]) and, after a barrier,
 // thread h adds the tile's column h up in row order (-> dpe[b][t][h], accumulated over the tiles in LDS).
-template <int NACC>
+// Elements are handled in groups of VEC consecutive h (VEC = 4 when H % 4 == 0 and the pointers are aligned);
+// NG = groups per thread and tile.
+template <int NG, int VEC>
 __global__ __launch_bounds__(kBlock) void k_fcj_bwd(const float* __restrict__ pe, const float* __restrict__ pd,
                                                     const float* __restrict__ dh, float* __restrict__ dpe,
                                                     float* __restrict__ partial, int T, int U1, int H, int rows,
@@ -95,45 +97,75 @@ __global__ __launch_bounds__(kBlock) void k_fcj_bwd(const float* __restrict__ pe
   __syncthreads();
   const float* pdb = pd + (size_t)b * U1 * H;
   float* part = partial + ((size_t)b * nchunk + chunk) * U1 * H;
+  auto ldv = [](const float* p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+      const f4v t = *reinterpret_cast<const f4v*>(p);
+      v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+      v[0] = p[0];
+    }
+  };
+  auto stv = [](float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+      const f4v t = {v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f4v*>(p) = t;
+    } else {
+      p[0] = v[0];
+    }
+  };
   for (int u0 = 0; u0 < U1; u0 += rows) {
-    const int nr = min(rows, U1 - u0), n = nr * H;
-    float acc[NACC], pdv[NACC];
-    int hcol[NACC];
+    const int nr = min(rows, U1 - u0), n = nr * H / VEC;  // groups in this tile
+    float acc[NG][VEC], pdv[NG][VEC];
+    int hcol[NG];
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) {
+    for (int k = 0; k < NG; ++k) {
       const int i = threadIdx.x + k * kBlock;
-      acc[k] = 0.f;
-      pdv[k] = (i < n) ? pdb[(size_t)u0 * H + i] : 0.f;
-      hcol[k] = i % H;
+      hcol[k] = (i * VEC) % H;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[k][e] = pdv[k][e] = 0.f;
+      if (i < n) ldv(pdb + (size_t)u0 * H + (size_t)i * VEC, pdv[k]);
     }
     for (int tt = 0; tt < nt; ++tt) {
       const float* src = dh + (((size_t)b * T + t0 + tt) * U1 + u0) * H;
-      float dv[NACC];
+      float dv[NG][VEC];
 #pragma unroll
-      for (int k = 0; k < NACC; ++k) {
+      for (int k = 0; k < NG; ++k) {
         const int i = threadIdx.x + k * kBlock;
-        dv[k] = (i < n) ? __builtin_nontemporal_load(src + i) : 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dv[k][e] = 0.f;
+        if (i < n) ldv(src + (size_t)i * VEC, dv[k]);
       }
 #pragma unroll
-      for (int k = 0; k < NACC; ++k) {
+      for (int k = 0; k < NG; ++k) {
         const int i = threadIdx.x + k * kBlock;
-        const float hh = tanh_fast(pe_s[tt * H + hcol[k]] + pdv[k]);
-        const float d = dv[k] * (1.f - hh * hh);
-        acc[k] += d;
-        if (i < n) tile[i] = d;
+        float pv[VEC], d[VEC];
+        ldv(pe_s + tt * H + hcol[k], pv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float hh = tanh_fast(pv[e] + pdv[k][e]);
+          d[e] = dv[k][e] * __builtin_fmaf(-hh, hh, 1.f);
+          acc[k][e] += d[e];
+        }
+        if (i < n) stv(tile + (size_t)i * VEC, d);
       }
       __syncthreads();
-      for (int hc = threadIdx.x; hc < H; hc += kBlock) {
-        float s = dpe_acc[tt * H + hc];
-        for (int r = 0; r < nr; ++r) s += tile[r * H + hc];
-        dpe_acc[tt * H + hc] = s;
+      for (int hc = threadIdx.x * VEC; hc < H; hc += kBlock * VEC) {
+        float sum[VEC];
+        ldv(dpe_acc + tt * H + hc, sum);
+        for (int r = 0; r < nr; ++r) {
+          float tv[VEC];
+          ldv(tile + r * H + hc, tv);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) sum[e] += tv[e];
+        }
+        stv(dpe_acc + tt * H + hc, sum);
       }
       __syncthreads();
     }
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) {
+    for (int k = 0; k < NG; ++k) {
       const int i = threadIdx.x + k * kBlock;
-      if (i < n) part[(size_t)u0 * H + i] = acc[k];
+      if (i < n) stv(part + (size_t)u0 * H + (size_t)i * VEC, acc[k]);
     }
   }
   for (int i = threadIdx.x; i < nt * H; i += kBlock) dpe[((size_t)b * T + t0) * H + i] = dpe_acc[i];
@@ -200,20 +232,28 @@ int rnnt_mi355x_fc_joint_backward(const float* pe, const float* pd, const float*
   const int rows = tile_rows(U1, H);
   const size_t lds = sizeof(float) * ((size_t)rows * H + 2 * (size_t)kFrames * H);
   float* partial = static_cast<float*>(workspace);
-  const int nacc = (rows * H + kBlock - 1) / kBlock;  // <= 32
+  const bool vec = H % 4 == 0 && (reinterpret_cast<uintptr_t>(pd) | reinterpret_cast<uintptr_t>(dh) |
+                                  reinterpret_cast<uintptr_t>(workspace)) % 16 == 0;
+  const int ng = (rows * H / (vec ? 4 : 1) + kBlock - 1) / kBlock;  // groups per thread and tile: <= 8 (vec) or 32
   const dim3 grid((unsigned)(B * nchunk));
-#define FCJ_BWD(N)                                                                                          \
+#define FCJ_BWD(N, V)                                                                                       \
   do {                                                                                                      \
     if (lds > 48 * 1024 &&                                                                                  \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcj_bwd<N>),                                   \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcj_bwd<N, V>),                                \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)           \
       return RNNT_MI355X_LAUNCH_FAILURE;                                                                    \
-    k_fcj_bwd<N><<<grid, kBlock, lds, st>>>(pe, pd, dh, dpe, partial, T, U1, H, rows, nchunk);              \
+    k_fcj_bwd<N, V><<<grid, kBlock, lds, st>>>(pe, pd, dh, dpe, partial, T, U1, H, rows, nchunk);           \
   } while (0)
-  if (nacc <= 4) FCJ_BWD(4);
-  else if (nacc <= 8) FCJ_BWD(8);
-  else if (nacc <= 16) FCJ_BWD(16);
-  else FCJ_BWD(32);
+  if (vec) {
+    if (ng <= 2) FCJ_BWD(2, 4);
+    else if (ng <= 4) FCJ_BWD(4, 4);
+    else FCJ_BWD(8, 4);
+  } else {
+    if (ng <= 4) FCJ_BWD(4, 1);
+    else if (ng <= 8) FCJ_BWD(8, 1);
+    else if (ng <= 16) FCJ_BWD(16, 1);
+    else FCJ_BWD(32, 1);
+  }
 #undef FCJ_BWD
   const long long total = (long long)B * U1 * H;
   k_fcj_bwd_reduce<<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, dpd, U1 * H, nchunk, total);
