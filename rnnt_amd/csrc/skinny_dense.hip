@@ -245,9 +245,18 @@ inline int avec_for(const void* p, int ncol) {
 inline bool nvec_ok(const void* p, int ncol, int nt) {
   return nt == 1 || (ncol % nt == 0 && reinterpret_cast<uintptr_t>(p) % (sizeof(float) * nt) == 0);
 }
-inline unsigned fwd_grid(long long M) {
+// Persistent grid of the forward kernel: as many blocks as are resident at once (the row tiles are dealt
+// round-robin, so a second, partial round of blocks would leave most of the device idle at the end).
+template <typename Kern>
+inline unsigned fwd_grid(long long M, Kern kern, size_t lds) {
   const long long blocks = ((M + 31) / 32 + 3) / 4;
-  return (unsigned)(blocks < 2048 ? blocks : 2048);  // persistent: 8 blocks per CU at most
+  int per_cu = 0, dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+    cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  const long long resident = (long long)per_cu * cus;
+  return (unsigned)(blocks < resident ? blocks : resident);
 }
 inline int wgrad_blocks(long long M) {
   const long long b = (M + 255) / 256;
@@ -266,13 +275,13 @@ int launch_fwd(const float* a, const float* z, const float* w, const float* bias
   }
   const bool yv = nvec_ok(y, Nd, nt);
   const size_t lds = sizeof(float) * (size_t)((Kd + 7) & ~7) * (32 * nt + 4);
-  const unsigned grid = fwd_grid(M);
 #define DENSE_FWD(NT, AV)                                                                                        \
   do {                                                                                                           \
     if (lds > 48 * 1024 &&                                                                                       \
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_fwd<NT, AV, DACT, TRANS>),                    \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
       return RNNT_MI355X_LAUNCH_FAILURE;                                                                         \
+    const unsigned grid = fwd_grid(M, k_dense_fwd<NT, AV, DACT, TRANS>, lds);                                    \
     k_dense_fwd<NT, AV, DACT, TRANS><<<grid, kBlock, lds, st>>>(a, z, w, bias, y, M, Kd, Nd, act, yv);           \
   } while (0)
 #define DENSE_FWD_AV(NT)              \
