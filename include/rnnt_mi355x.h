@@ -100,6 +100,23 @@ int rnnt_mi355x_backward_strided(const float* logits, size_t logits_batch_stride
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
                                  const float* grad_scale, void* workspace, void* hip_stream);
 
+/* The crop itself as an argument: logits_full / grad_full are dense
+ * [B, T0, maxU1, V] tensors and the lattice uses frames t_offset .. T0-1 of every
+ * utterance (`acts[:, shift:, :, :]`, `input_length -= shift` at reference
+ * util.py:62-64; in_len counts frames of the crop, the workspace is the one of
+ * rnnt_mi355x_workspace_bytes(B, T0 - t_offset, maxU1)).  The backward writes
+ * zeros into the t_offset skipped frames of grad_full (which may be
+ * logits_full itself).  Unlike the *_strided forms this tells the library
+ * that the tensor is dense, which the small-vocabulary kernels (V <= 64: the
+ * reference's own 40/62-symbol vocabularies) need. */
+int rnnt_mi355x_forward_cropped(const float* logits_full, const int32_t* labels, const int32_t* in_len,
+                                const int32_t* lab_len, int B, int T0, int t_offset, int maxU1, int V, int blank,
+                                float* costs, void* workspace, void* hip_stream);
+int rnnt_mi355x_backward_cropped(const float* logits_full, float* grad_full, const int32_t* labels,
+                                 const int32_t* in_len, const int32_t* lab_len, int B, int T0, int t_offset,
+                                 int maxU1, int V, int blank, const float* grad_scale, void* workspace,
+                                 void* hip_stream);
+
 /* forward + backward_inplace in one call: what one training step of
  * reference rnnt/train.py:151-157 spends in the loss layer. */
 int rnnt_mi355x_loss_grad(float* logits_inout, const int32_t* labels, const int32_t* in_len, const int32_t* lab_len,

@@ -32,6 +32,8 @@ _SIGNATURES = {
     "rnnt_mi355x_backward": (ctypes.c_int, [_vp] * 5 + _META + [_vp, _vp, _vp]),
     "rnnt_mi355x_forward_strided": (ctypes.c_int, [_vp, _sz] + [_vp] * 3 + _META + [_vp, _vp, _vp]),
     "rnnt_mi355x_backward_strided": (ctypes.c_int, [_vp, _sz, _vp, _sz] + [_vp] * 3 + _META + [_vp, _vp, _vp]),
+    "rnnt_mi355x_forward_cropped": (ctypes.c_int, [_vp] * 4 + [_i] * 6 + [_vp, _vp, _vp]),
+    "rnnt_mi355x_backward_cropped": (ctypes.c_int, [_vp] * 5 + [_i] * 6 + [_vp, _vp, _vp]),
     "rnnt_mi355x_backward_inplace": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp]),
     "rnnt_mi355x_loss_grad": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp]),
     "rnnt_mi355x_loss_grad_events": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp, _vp, _vp]),

@@ -767,22 +767,29 @@ constexpr int kSmallNld = kSmallMaxV * 64 / 4 / 64;  // float4 loads per lane pe
 
 struct SmallGeom {
   int B, maxT, maxU1, V, blank;
+  int frames;            // frames per utterance in memory = t_off + maxT
+  int t_off;             // leading frames of every utterance that take no part in the lattice (a crop along T)
   int ntiles_full;       // tiles of 64 whole rows
-  long long total_rows;  // B*maxT*maxU1
+  long long total_rows;  // B*frames*maxU1
 };
 
 // b, T, U are in/out: the lengths are reloaded only when the lane's utterance changes (rarely), so that
 // decoding a tile does not wait on memory.
+// in_range: the row is a frame of the lattice's [maxT, maxU1] grid (inside the tensor and not a cropped frame);
+// t is then its frame index in the crop.
 __device__ __forceinline__ void small_decode(long long row, const SmallGeom& g, const int32_t* in_len,
                                              const int32_t* lab_len, int& b, int& t, int& u, int& T, int& U,
                                              bool& in_range) {
-  in_range = row < g.total_rows;
-  const unsigned r = in_range ? (unsigned)row : 0u;
-  const unsigned per_b = (unsigned)g.maxT * (unsigned)g.maxU1;
+  const bool in_tensor = row < g.total_rows;
+  const unsigned r = in_tensor ? (unsigned)row : 0u;
+  const unsigned per_b = (unsigned)g.frames * (unsigned)g.maxU1;
   const int nb = (int)(r / per_b);
   const unsigned rem = r - (unsigned)nb * per_b;
-  t = (int)(rem / (unsigned)g.maxU1);
-  u = (int)(rem - (unsigned)t * (unsigned)g.maxU1);
+  const int tf = (int)(rem / (unsigned)g.maxU1);
+  u = (int)(rem - (unsigned)tf * (unsigned)g.maxU1);
+  t = tf - g.t_off;
+  in_range = in_tensor & (t >= 0);
+  t = max(t, 0);
   if (nb != b) {
     b = nb;
     utt_dims(in_len, lab_len, b, g.maxT, g.maxU1, T, U);
@@ -1106,8 +1113,8 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
     int b = -1, t, u, T = 0, U = 0;
     bool in_range;
     small_decode(row, g, in_len, lab_len, b, t, u, T, U, in_range);
-    if (in_range) {
-      const float4 c = cell_coef(cell_load(w, labels, b, t, u, T, U, g.maxT, g.maxU1, V, true));
+    if (row < g.total_rows) {
+      const float4 c = cell_coef(cell_load(w, labels, b, t, u, T, U, g.maxT, g.maxU1, V, in_range));
       float* gp = grad + (size_t)row * V;
       if (c.x > -INFINITY) {
         sqsum += small_row_grad<1>(x + (size_t)row * V, gp, V, g.blank, c, grad_scale ? grad_scale[b] : 1.f);
@@ -1820,6 +1827,15 @@ __global__ __launch_bounds__(256) void k_joint_fix_g(const float* __restrict__ f
   }
 }
 
+// zeroes the first n floats of every utterance (the frames a crop along T leaves out of the lattice)
+__global__ __launch_bounds__(256) void k_zero_frames(float* __restrict__ g, size_t batch_stride, size_t n) {
+  float* p = g + (size_t)blockIdx.y * batch_stride;
+  const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (i0 + k < n) p[i0 + k] = 0.f;
+}
+
 __global__ __launch_bounds__(64) void k_init(Ws w, int n_partial) {
   if (threadIdx.x == 0) {
     w.hdr->flags = 0;
@@ -1932,6 +1948,8 @@ struct Call {
   const int32_t* lab_len;
   int B, maxT, maxU1, V, blank;
   size_t xstride, gstride;  // elements between utterances in logits / grad
+  int t_off = 0;            // crop: the lattice starts at frame t_off of [B, t_off + maxT, maxU1, V] tensors whose
+                            // frame 0 is logits - t_off*maxU1*V (and grad likewise); 0 = no such promise
   const float* grad_scale;
   float* costs;
   Ws w;
@@ -1949,16 +1967,21 @@ RowCfg sub_cfg(const Call& c, const void* p1, int b0, int nb) {
 }
 
 // Small-vocabulary path: V <= 64 and 16-byte aligned buffers (a tile of 64 rows is then a whole number of float4).
+// The small-vocabulary kernels tile the tensor in runs of 64 rows across utterance boundaries: it has to be
+// dense, possibly with t_off leading frames per utterance that are not part of the lattice.
 bool use_small(const Call& c, const void* p1) {
-  const uintptr_t a = reinterpret_cast<uintptr_t>(c.logits) | reinterpret_cast<uintptr_t>(p1);
-  const size_t dense = (size_t)c.maxT * c.maxU1 * c.V;  // its tiles run across utterance boundaries
+  const size_t frame = (size_t)c.maxU1 * c.V;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(c.logits - c.t_off * frame) |
+                      (p1 ? reinterpret_cast<uintptr_t>(static_cast<const float*>(p1) - c.t_off * frame) : 0);
+  const size_t dense = (size_t)(c.t_off + c.maxT) * frame;
   return c.V <= kSmallMaxV && a % 16 == 0 && c.xstride == dense && c.gstride == dense;
 }
 
 SmallGeom small_geom(const Call& c, int* blocks) {
   SmallGeom g;
   g.B = c.B; g.maxT = c.maxT; g.maxU1 = c.maxU1; g.V = c.V; g.blank = c.blank;
-  g.total_rows = (long long)c.B * c.maxT * c.maxU1;
+  g.frames = c.t_off + c.maxT; g.t_off = c.t_off;
+  g.total_rows = (long long)c.B * g.frames * c.maxU1;
   g.ntiles_full = (int)(g.total_rows / 64);
   long long want = (g.ntiles_full + kSmallWaves - 1) / kSmallWaves;
   // persistent grid, exactly one resident round: tiles are dealt round-robin to the waves.  Residency per CU is
@@ -1981,9 +2004,10 @@ void launch_lse(const Call& c, int b0, int nb, hipStream_t st) {
     int blocks;
     const SmallGeom g = small_geom(c, &blocks);
     const size_t lds = sizeof(float4) * 16 * (size_t)c.V * kSmallWaves;
-    if (c.V % 4 == 0) k_lse_small<4><<<blocks, kSmallBlock, lds, st>>>(c.logits, c.labels, c.in_len, c.lab_len, g, c.w);
-    else if (c.V % 2 == 0) k_lse_small<2><<<blocks, kSmallBlock, lds, st>>>(c.logits, c.labels, c.in_len, c.lab_len, g, c.w);
-    else k_lse_small<1><<<blocks, kSmallBlock, lds, st>>>(c.logits, c.labels, c.in_len, c.lab_len, g, c.w);
+    const float* x0 = c.logits - (size_t)c.t_off * c.maxU1 * c.V;  // frame 0 of the uncropped tensor
+    if (c.V % 4 == 0) k_lse_small<4><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
+    else if (c.V % 2 == 0) k_lse_small<2><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
+    else k_lse_small<1><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
     return;
   }
   const RowCfg cfg = sub_cfg(c, c.logits, b0, nb);
@@ -2006,10 +2030,18 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
     int blocks;
     const SmallGeom g = small_geom(c, &blocks);
     const size_t lds = sizeof(float4) * 16 * (size_t)c.V * kSmallWaves;
-    if (c.V % 4 == 0) k_grad_small<4><<<blocks, kSmallBlock, lds, st>>>(c.logits, c.grad, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
-    else if (c.V % 2 == 0) k_grad_small<2><<<blocks, kSmallBlock, lds, st>>>(c.logits, c.grad, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
-    else k_grad_small<1><<<blocks, kSmallBlock, lds, st>>>(c.logits, c.grad, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
+    const size_t skip = (size_t)c.t_off * c.maxU1 * c.V;  // the cropped frames are rows without a cell: zero-filled
+    const float* x0 = c.logits - skip;
+    float* g0 = c.grad - skip;
+    if (c.V % 4 == 0) k_grad_small<4><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
+    else if (c.V % 2 == 0) k_grad_small<2><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
+    else k_grad_small<1><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
     return;
+  }
+  if (c.t_off > 0 && b0 == 0) {  // gradient of the cropped frames
+    const size_t n = (size_t)c.t_off * c.maxU1 * c.V;
+    const unsigned per_b = (unsigned)((n + 1023) / 1024);
+    k_zero_frames<<<dim3(per_b, (unsigned)c.B), 256, 0, st>>>(c.grad - n, c.gstride, n);
   }
   const RowCfg cfg = sub_cfg(c, c.grad, b0, nb);
   RNNT_DISPATCH(k_grad, cfg, sizeof(float4) * (size_t)cfg.gm.TT * c.maxU1, c.logits, c.grad, c.labels, c.in_len,
@@ -2043,9 +2075,11 @@ int launch_loss_grad(const Call& c, hipStream_t st, hipEvent_t ev_begin, hipEven
 
 int make_call(Call* c, const float* logits, float* grad, const int32_t* labels, const int32_t* in_len,
               const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank, const float* grad_scale,
-              float* costs, void* workspace, bool need_grad, bool need_costs, size_t xstride = 0, size_t gstride = 0) {
+              float* costs, void* workspace, bool need_grad, bool need_costs, size_t xstride = 0, size_t gstride = 0,
+              int t_off = 0) {
   const int rc = check_shape(B, maxT, maxU1, V, blank);
   if (rc != RNNT_MI355X_OK) return rc;
+  c->t_off = t_off;
   const size_t dense = (size_t)maxT * maxU1 * V;
   if ((xstride && xstride < dense) || (gstride && gstride < dense)) return RNNT_MI355X_INVALID_VALUE;
   c->xstride = xstride ? xstride : dense;
@@ -2231,6 +2265,34 @@ int rnnt_mi355x_backward_strided(const float* logits, size_t logits_batch_stride
   Call c;
   const int rc = make_call(&c, logits, grad, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale, nullptr,
                            workspace, true, false, logits_batch_stride, grad_batch_stride);
+  if (rc != RNNT_MI355X_OK) return rc;
+  return launch_backward(c, static_cast<hipStream_t>(hip_stream));
+}
+
+int rnnt_mi355x_forward_cropped(const float* logits_full, const int32_t* labels, const int32_t* in_len,
+                                const int32_t* lab_len, int B, int T0, int t_offset, int maxU1, int V, int blank,
+                                float* costs, void* workspace, void* hip_stream) {
+  if (t_offset < 0 || t_offset >= T0 || !logits_full) return RNNT_MI355X_INVALID_VALUE;
+  if ((long long)B * T0 * maxU1 >= (1LL << 31)) return RNNT_MI355X_UNSUPPORTED_SIZE;
+  const size_t frame = (size_t)maxU1 * V, stride = (size_t)T0 * frame;
+  Call c;
+  const int rc = make_call(&c, logits_full + t_offset * frame, nullptr, labels, in_len, lab_len, B, T0 - t_offset,
+                           maxU1, V, blank, nullptr, costs, workspace, false, true, stride, stride, t_offset);
+  if (rc != RNNT_MI355X_OK) return rc;
+  return launch_forward(c, static_cast<hipStream_t>(hip_stream));
+}
+
+int rnnt_mi355x_backward_cropped(const float* logits_full, float* grad_full, const int32_t* labels,
+                                 const int32_t* in_len, const int32_t* lab_len, int B, int T0, int t_offset,
+                                 int maxU1, int V, int blank, const float* grad_scale, void* workspace,
+                                 void* hip_stream) {
+  if (t_offset < 0 || t_offset >= T0 || !logits_full || !grad_full) return RNNT_MI355X_INVALID_VALUE;
+  if ((long long)B * T0 * maxU1 >= (1LL << 31)) return RNNT_MI355X_UNSUPPORTED_SIZE;
+  const size_t frame = (size_t)maxU1 * V, stride = (size_t)T0 * frame;
+  Call c;
+  const int rc = make_call(&c, logits_full + t_offset * frame, grad_full + t_offset * frame, labels, in_len, lab_len,
+                           B, T0 - t_offset, maxU1, V, blank, grad_scale, nullptr, workspace, true, false, stride,
+                           stride, t_offset);
   if (rc != RNNT_MI355X_OK) return rc;
   return launch_backward(c, static_cast<hipStream_t>(hip_stream));
 }

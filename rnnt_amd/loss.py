@@ -104,9 +104,14 @@ class _RNNTLossFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws = _workspace(B, T, U1, dev)
             costs = torch.empty(B, dtype=torch.float32, device=dev)
-            rc = _lib.lib().rnnt_mi355x_forward_strided(_ptr(view), bstride, _ptr(labels), _ptr(il), _ptr(ll), B, T, U1,
-                                                        V, blank, _ptr(costs), _ptr(ws), _stream_ptr(dev))
-            _lib.check(rc, "rnnt_mi355x_forward_strided")
+            if acts_full.is_contiguous():  # dense: the crop goes down as an argument
+                rc = _lib.lib().rnnt_mi355x_forward_cropped(_ptr(acts_full), _ptr(labels), _ptr(il), _ptr(ll), B, T0,
+                                                            t_offset, U1, V, blank, _ptr(costs), _ptr(ws),
+                                                            _stream_ptr(dev))
+            else:
+                rc = _lib.lib().rnnt_mi355x_forward_strided(_ptr(view), bstride, _ptr(labels), _ptr(il), _ptr(ll), B, T,
+                                                            U1, V, blank, _ptr(costs), _ptr(ws), _stream_ptr(dev))
+            _lib.check(rc, "rnnt_mi355x_forward")
             if check_inputs:
                 _raise_on_flags(ws, dev)
         ctx.acts, ctx.labels, ctx.il, ctx.ll, ctx.ws = acts_full, labels, il, ll, ws
@@ -125,15 +130,20 @@ class _RNNTLossFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             scale = grad_costs.to(device=dev, dtype=torch.float32).reshape(B).contiguous()
             grad_full = acts_full if ctx.inplace else torch.empty(acts_full.shape, dtype=torch.float32, device=dev)
-            view, gview = acts_full[:, t_offset:], grad_full[:, t_offset:]
-            xs = view.stride(0) if B > 1 else T * U1 * V
-            gs = gview.stride(0) if B > 1 else T * U1 * V
-            rc = _lib.lib().rnnt_mi355x_backward_strided(_ptr(view), xs, _ptr(gview), gs, _ptr(ctx.labels), _ptr(ctx.il),
-                                                         _ptr(ctx.ll), B, T, U1, V, ctx.blank, _ptr(scale), _ptr(ctx.ws),
-                                                         _stream_ptr(dev))
-            _lib.check(rc, "rnnt_mi355x_backward_strided")
-            if t_offset:
-                grad_full[:, :t_offset].zero_()  # the cropped frames take no part in the loss
+            if acts_full.is_contiguous():  # the library zero-fills the cropped frames itself
+                rc = _lib.lib().rnnt_mi355x_backward_cropped(_ptr(acts_full), _ptr(grad_full), _ptr(ctx.labels),
+                                                             _ptr(ctx.il), _ptr(ctx.ll), B, T0, t_offset, U1, V, ctx.blank,
+                                                             _ptr(scale), _ptr(ctx.ws), _stream_ptr(dev))
+            else:
+                view, gview = acts_full[:, t_offset:], grad_full[:, t_offset:]
+                xs = view.stride(0) if B > 1 else T * U1 * V
+                gs = gview.stride(0) if B > 1 else T * U1 * V
+                rc = _lib.lib().rnnt_mi355x_backward_strided(_ptr(view), xs, _ptr(gview), gs, _ptr(ctx.labels),
+                                                             _ptr(ctx.il), _ptr(ctx.ll), B, T, U1, V, ctx.blank,
+                                                             _ptr(scale), _ptr(ctx.ws), _stream_ptr(dev))
+                if t_offset:
+                    grad_full[:, :t_offset].zero_()  # the cropped frames take no part in the loss
+            _lib.check(rc, "rnnt_mi355x_backward")
         ctx.acts = ctx.ws = None
         return grad_full, None, None, None, None, None, None, None
 

@@ -340,3 +340,32 @@ def test_entry_points_can_be_captured_in_a_hip_graph():
     np.testing.assert_allclose(costs.cpu().numpy(), co, rtol=COST_RTOL)
     assert np.abs(buf.cpu().numpy() - go).max() < GRAD_ATOL
     np.testing.assert_allclose(scal.cpu().numpy()[0], co.sum(), rtol=COST_RTOL)
+
+
+# B, T0, t_offset, U, V, blank: small-vocabulary tiles (64 rows) with cropped frames inside full tiles, inside the
+# last partial tile only, and a large vocabulary (generic kernels + zero-fill of the cropped frames)
+CROP_SHAPES = [(2, 3, 2, 0, 5, 0), (3, 9, 2, 4, 62, 39), (2, 40, 3, 7, 40, 39), (1, 5, 4, 2, 16, 1), (2, 7, 2, 3, 300, 7),
+               (2, 6, 1, 3, 1024, 0)]
+
+
+@pytest.mark.parametrize("B,T0,off,U,V,blank", CROP_SHAPES)
+@pytest.mark.parametrize("inplace", [False, True])
+def test_crop_along_t_is_done_inside_the_library(B, T0, off, U, V, blank, inplace):
+    rng = np.random.default_rng(B + T0 + U + V)
+    x = rng.standard_normal((B, T0, U + 1, V)).astype(np.float32)
+    lab = rng.integers(0, V - 1, (B, max(U, 1))).astype(np.int32)[:, :U]
+    lab[lab >= blank] += 1
+    T = T0 - off
+    il = rng.integers(1, T + 1, B).astype(np.int32)
+    ll = rng.integers(0, U + 1, B).astype(np.int32)
+    il[0], ll[0] = T, U
+    co, go = orc.rnnt_loss_and_grad(x[:, off:], lab if U else np.zeros((B, 0), np.int32), il, ll, blank)
+    base = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    acts = base * 1.0 if inplace else base
+    labels = torch.from_numpy(lab).to(DEV) if U else torch.zeros((B, 0), dtype=torch.int32, device=DEV)
+    costs = rnnt_amd.rnnt_loss(acts, labels, il, ll, blank, t_offset=off, inplace=inplace)
+    costs.sum().backward()
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+    g = base.grad.cpu().numpy()
+    assert not g[:, :off].any()                      # the cropped frames (util.py:63)
+    assert np.abs(g[:, off:] - go).max() < GRAD_ATOL
