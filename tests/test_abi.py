@@ -65,3 +65,48 @@ def test_python_layer_refuses_cpu_tensors():
     acts = torch.zeros(1, 3, 2, 5)
     with pytest.raises(RuntimeError, match="no CPU path"):
         rnnt_amd.rnnt_loss(acts, torch.zeros(1, 1, dtype=torch.int32), torch.tensor([3]), torch.tensor([1]), 0)
+
+
+def test_new_entry_points_validate_without_a_gpu():
+    L = _lib.lib()
+    one = ctypes.c_void_p(256)  # never dereferenced: validation fails first
+    out = ctypes.c_size_t(0)
+    # fused joint: the workspace depends on V and V is limited
+    assert _lib.joint_workspace_bytes(4, 50, 11, 62) > _lib.workspace_bytes(4, 50, 11)
+    assert _lib.joint_workspace_bytes(4, 50, 11, 1024) > _lib.joint_workspace_bytes(4, 50, 11, 62)
+    assert L.rnnt_mi355x_joint_workspace_bytes(1, 4, 4, 4097, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE
+    assert L.rnnt_mi355x_joint_forward(None, 0, one, one, one, one, 1, 2, 2, 4, 0, one, one, None) == _lib.INVALID_VALUE
+    # crop as an argument
+    assert L.rnnt_mi355x_forward_cropped(one, one, one, one, 1, 4, 4, 2, 4, 0, one, one, None) == _lib.INVALID_VALUE  # nothing left
+    assert L.rnnt_mi355x_forward_cropped(one, one, one, one, 1, 4, -1, 2, 4, 0, one, one, None) == _lib.INVALID_VALUE
+    assert L.rnnt_mi355x_backward_cropped(one, None, one, one, one, 1, 4, 2, 2, 4, 0, None, one, None) == _lib.INVALID_VALUE
+    # FC-joint first layer and Dense layers
+    assert _lib.fc_joint_workspace_bytes(2, 17, 5, 100) == 4 * 2 * 3 * 5 * 100   # ceil(17 / 8) frame chunks
+    assert L.rnnt_mi355x_fc_joint_workspace_bytes(1, 1, 1, 1537, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE
+    assert L.rnnt_mi355x_fc_joint_backward(one, one, one, 1, 1, 1, 4, one, one, None, None) == _lib.INVALID_VALUE
+    assert _lib.dense_workspace_bytes(1000, 100, 62) > 0
+    assert L.rnnt_mi355x_dense_workspace_bytes(10, 129, 4, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE
+    assert L.rnnt_mi355x_dense_forward(one, one, None, 0, 4, 4, 0, one, None) == _lib.INVALID_VALUE
+    assert L.rnnt_mi355x_dense_backward(one, one, None, one, 8, 4, 4, 1, one, one, one, one, None) == _lib.INVALID_VALUE  # tanh needs y
+    # decoder step
+    assert L.rnnt_mi355x_joint_log_softmax(one, 2, one, 2, None, None, 3, 8, one, one, None) == _lib.INVALID_VALUE  # 3 rows from 2
+    assert L.rnnt_mi355x_joint_log_softmax(one, 2, None, 0, None, None, 2, 0, one, one, None) == _lib.INVALID_VALUE
+
+
+def test_host_side_helpers_without_a_gpu():
+    import numpy as np
+    import torch
+    import rnnt_amd
+    from oracle import rnnt_oracle as orc
+    yt, yp = torch.randn(2, 5, 3), torch.randn(2, 4, 2)
+    np.testing.assert_array_equal(rnnt_amd.concatenate_lambda([yt, yp]).numpy(),
+                                  orc.concatenate_lambda(yt.numpy(), yp.numpy()).astype(np.float32))
+    with pytest.raises(ValueError, match="no CPU path"):
+        rnnt_amd.fc_joint_first_layer(torch.zeros(1, 2, 4), torch.zeros(1, 3, 4))
+    with pytest.raises(ValueError, match="no CPU path"):
+        rnnt_amd.joint_log_softmax(torch.zeros(2, 4))
+    with pytest.raises(ValueError, match="no CPU path"):
+        rnnt_amd.joint_dense(torch.zeros(3, 4), torch.zeros(4, 2), torch.zeros(2))
+    with pytest.raises(ValueError):
+        rnnt_amd.fc_joint(yt, yp, [(torch.zeros(7, 3), torch.zeros(3))])   # first kernel must have He + Hd rows
+    assert rnnt_amd.softmax(torch.zeros(5), is_log=True, axis=0).tolist() == [1.0] * 5   # reference quirk, no GPU needed
