@@ -33,8 +33,8 @@
  *     except rnnt_mi355x_read_status, none synchronises;
  *   - every function returns an rnnt_mi355x_status; nothing throws or aborts.
  *
- * Limits: 1 <= maxU1 <= 512, B*maxT*maxU1 < 2^31, V >= 1.  Element offsets
- * into logits are 64-bit.
+ * Limits: 1 <= maxU1 <= 512, B*maxT*maxU1 < 2^31, (maxT+2)*maxU1 < 2^28,
+ * V >= 1.  Element offsets into logits are 64-bit.
  */
 #ifndef RNNT_MI355X_H_
 #define RNNT_MI355X_H_
@@ -49,7 +49,7 @@ extern "C" {
 typedef enum {
   RNNT_MI355X_OK = 0,
   RNNT_MI355X_INVALID_VALUE = 1,    /* null pointer, non-positive size, blank outside [0,V) ... */
-  RNNT_MI355X_UNSUPPORTED_SIZE = 2, /* maxU1 > 512 or B*maxT*maxU1 >= 2^31 */
+  RNNT_MI355X_UNSUPPORTED_SIZE = 2, /* beyond a limit stated in this header */
   RNNT_MI355X_LAUNCH_FAILURE = 3,   /* HIP reported an error at launch/copy */
   RNNT_MI355X_BAD_INPUT_DATA = 4    /* device-side validation failed (see read_status) */
 } rnnt_mi355x_status;

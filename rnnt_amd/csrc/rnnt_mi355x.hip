@@ -440,8 +440,9 @@ __device__ __forceinline__ void load_lp_diag(const float4* rec0, int d, int maxT
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const int t1 = min(max(d - ucol[i], -1), maxT) + 1;                    // frame index incl. guards (v_med3_i32)
-    const unsigned off = (unsigned)(t1 * maxU1 + uoff[i]);                 // uoff = min(u, maxU1-1), or a guard slot
-    const float2 q = *reinterpret_cast<const float2*>(rec0 + off);
+    // 24-bit multiply-add (full rate; t1 <= maxT + 1 < 2^24, maxU1 <= 512), 32-bit byte offset from a uniform base
+    const unsigned off = __umul24((unsigned)t1, (unsigned)maxU1) + (unsigned)uoff[i];  // uoff = min(u, maxU1-1) or a guard slot
+    const float2 q = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rec0) + (size_t)(off << 4));
     pb[i] = q.x;
     pl[i] = q.y;
   }
@@ -1935,6 +1936,8 @@ int check_shape(int B, int maxT, int maxU1, int V, int blank) {
   if (blank < 0 || blank >= V) return RNNT_MI355X_INVALID_VALUE;
   if (maxU1 > kMaxU1) return RNNT_MI355X_UNSUPPORTED_SIZE;
   if ((long long)B * maxT * maxU1 >= (1LL << 31)) return RNNT_MI355X_UNSUPPORTED_SIZE;
+  // the sweeps address an utterance's records with 32-bit byte offsets and 24-bit frame indices
+  if (((long long)maxT + 2) * maxU1 >= (1LL << 28) || maxT >= (1 << 24) - 2) return RNNT_MI355X_UNSUPPORTED_SIZE;
   return RNNT_MI355X_OK;
 }
 
