@@ -369,3 +369,25 @@ def test_crop_along_t_is_done_inside_the_library(B, T0, off, U, V, blank, inplac
     g = base.grad.cpu().numpy()
     assert not g[:, :off].any()                      # the cropped frames (util.py:63)
     assert np.abs(g[:, off:] - go).max() < GRAD_ATOL
+
+
+@pytest.mark.parametrize("scale", [8.0, 25.0])
+def test_fused_joint_with_peaked_outputs(scale):
+    """Trained networks emit logits with a large spread: most of exp(f - max f) and exp(g - max g) is tiny or
+    zero, some cells fall under the linear-domain floor and take the exponent-domain route."""
+    B, T, U, V, blank = 2, 45, 9, 62, 39
+    rng = np.random.default_rng(int(scale))
+    f = (rng.standard_normal((B, T, V)) * scale).astype(np.float32)
+    g = (rng.standard_normal((B, U + 1, V)) * scale).astype(np.float32)
+    lab = rng.integers(0, V - 1, (B, U)).astype(np.int32)
+    lab[lab >= blank] += 1
+    il, ll = np.array([T, T - 11], np.int32), np.array([U, 5], np.int32)
+    joint = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
+    co, gj = orc.rnnt_loss_and_grad(joint, lab, il, ll, blank)
+    tf_ = torch.from_numpy(f).to(DEV).requires_grad_(True)
+    tg = torch.from_numpy(g).to(DEV).requires_grad_(True)
+    costs = rnnt_amd.rnnt_joint_loss(tf_, tg, lab, il, ll, blank)
+    costs.sum().backward()
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+    assert np.abs(tf_.grad.cpu().numpy() - gj.sum(2)).max() < GRAD_ATOL
+    assert np.abs(tg.grad.cpu().numpy() - gj.sum(1)).max() < GRAD_ATOL
