@@ -71,6 +71,9 @@ struct Ws {
   float* Gp;       // [B] rows u < U1p, columns v < Vp:  2^(g*log2e - mg2)
   float* Ctu;      // [B] rows t < Tp,  columns u < U1p: C = s_b * gamma / (cell sum); 0 where nothing flows through the products
   float* Cut;      // [B] rows u < U1p, columns t < Tp:  the same numbers transposed
+  int* head_of;    // [B][Vp]       first position u whose target symbol is v (the blank's is U_b + 1), or -1
+  int* nxt;        // [B][maxU1+2]  next position with the same target as position u, or -1
+  float* rowpart;  // [B][Tp][U1p/32] sums of s*pb(t,u) over runs of 32 positions
   int Vp, U1p, Tp; // padded extents: maxT and maxU1 rounded up to 32, V to 32 / 64 / a multiple of 128
   size_t partial_off;
   int D;    // diagonals = maxT + maxU1 - 1
@@ -111,6 +114,9 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
   const size_t o_Gp = joint ? take(sizeof(float) * (size_t)B * U1p * Vp) : 0;
   const size_t o_Ctu = joint ? take(sizeof(float) * (size_t)B * Tp * U1p) : 0;
   const size_t o_Cut = joint ? take(sizeof(float) * (size_t)B * Tp * U1p) : 0;
+  const size_t o_head = joint ? take(sizeof(int) * (size_t)B * Vp) : 0;
+  const size_t o_nxt = joint ? take(sizeof(int) * (size_t)B * (maxU1 + 2)) : 0;
+  const size_t o_rowpart = joint ? take(sizeof(float) * (size_t)B * Tp * (U1p / 32)) : 0;
   if (w) {
     w->hdr = reinterpret_cast<Header*>(p + o_hdr);
     w->ll = reinterpret_cast<double*>(p + o_ll);
@@ -125,6 +131,9 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
     w->Gp = joint ? reinterpret_cast<float*>(p + o_Gp) : nullptr;
     w->Ctu = joint ? reinterpret_cast<float*>(p + o_Ctu) : nullptr;
     w->Cut = joint ? reinterpret_cast<float*>(p + o_Cut) : nullptr;
+    w->head_of = joint ? reinterpret_cast<int*>(p + o_head) : nullptr;
+    w->nxt = joint ? reinterpret_cast<int*>(p + o_nxt) : nullptr;
+    w->rowpart = joint ? reinterpret_cast<float*>(p + o_rowpart) : nullptr;
     w->Vp = Vp; w->U1p = U1p; w->Tp = Tp;
     w->partial_off = o_partial;
     w->D = D;
@@ -1156,7 +1165,9 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
 //   k_joint_lse_mm  S -> records {lpb, lpl, log2 S}          (then k_sweep as usual)
 //   k_joint_coef    {c, pb, pl, label code} and C of every cell from alpha, beta, ll
 //   k_joint_df_mm, k_joint_dg_mm   the two gradient contractions
-//   k_joint_corr_f, k_joint_corr_g the blank / label terms
+//   k_joint_labelmap               chains of label positions per symbol: the blank / label terms of d f are
+//                                  subtracted in the epilogue of its contraction
+//   k_joint_corr_g                 the blank / label terms of d g
 //   k_joint_fix_f, k_joint_fix_g   exponent-domain contributions of flagged cells (exit at once when there are none)
 // ---------------------------------------------------------------------------
 struct JointGeom {
@@ -1194,7 +1205,8 @@ __device__ __forceinline__ void jrow_load(const float* row, int V, int lane, flo
 // tiled layout.  Lane = (row q of 4, column chunk cc of 8, half e4 of a chunk): one step reads 256 contiguous
 // bytes of each of the 4 rows and writes 8 whole 128-byte lines.  Padding rows and columns become zeros.
 // VEC4: rows start on 16-byte boundaries (V % 4 == 0, aligned bases), so the reads are float4.
-template <bool VEC4>
+// NIT > 0: the rows stay in registers between the two passes (NIT float4 per lane, V <= 256 * NIT).
+template <bool VEC4, int NIT>
 __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f, const float* __restrict__ g,
                                                     JointGeom jg, Ws w) {
   const int lane = threadIdx.x & 63;
@@ -1224,22 +1236,41 @@ __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f,
       }
     }
   };
+  constexpr int NKEEP = NIT > 0 ? NIT : 1;
+  float keep[NKEEP][4];
   float m = -INFINITY;
-  for (int c = cc; c < chunks; c += 8) {
-    float x[4];
-    load4(c * 8 + e4, x);
-    m = fmaxf(fmaxf(m, fmaxf(x[0], x[1])), fmaxf(x[2], x[3]));
+  if (NIT > 0) {
+#pragma unroll
+    for (int it = 0; it < NKEEP; ++it) {
+      load4((cc + 8 * it) * 8 + e4, keep[it]);  // chunks past the padded row load as -inf
+      m = fmaxf(fmaxf(m, fmaxf(keep[it][0], keep[it][1])), fmaxf(keep[it][2], keep[it][3]));
+    }
+  } else {
+    for (int c = cc; c < chunks; c += 8) {
+      float x[4];
+      load4(c * 8 + e4, x);
+      m = fmaxf(fmaxf(m, fmaxf(x[0], x[1])), fmaxf(x[2], x[3]));
+    }
   }
   m = group_max<16>(m) * kLog2e;  // the 16 lanes of a row are one DPP row
   if ((lane & 15) == 0 && row_ok) (isf ? w.mf2 + b * jg.maxT : w.mg2 + b * jg.maxU1)[row] = m;
   float* out = (isf ? w.Fp : w.Gp) + (size_t)b * R * w.Vp + tiled_off(row, e4, chunks);
-  for (int c = cc; c < chunks; c += 8) {
-    float x[4];
-    load4(c * 8 + e4, x);
+  auto emit = [&](int c, const float (&x)[4]) {
     f4v y;
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[i] = row_ok ? fast_exp2(__builtin_fmaf(x[i], kLog2e, -m)) : 0.f;  // 2^-inf = 0
     *reinterpret_cast<f4v*>(out + ((size_t)c << 8)) = y;
+  };
+  if (NIT > 0) {
+#pragma unroll
+    for (int it = 0; it < NKEEP; ++it)
+      if (cc + 8 * it < chunks) emit(cc + 8 * it, keep[it]);
+  } else {
+    for (int c = cc; c < chunks; c += 8) {
+      float x[4];
+      load4(c * 8 + e4, x);
+      emit(c, x);
+    }
   }
 }
 
@@ -1450,7 +1481,7 @@ __global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ 
   const int t0 = (r / ub) * 8, u0 = (r - (r / ub) * ub) * 32;
   const int tt = threadIdx.x >> 5, uu = threadIdx.x & 31;
   const int t = t0 + tt, u = u0 + uu;
-  float cm = 0.f;
+  float cm = 0.f, pbv = 0.f;
   if (t < jg.maxT && u < jg.maxU1) {
     int T, U;
     utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
@@ -1463,8 +1494,12 @@ __global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ 
     const bool flagged = live && raw.rc.w != 0.f;
     cf.w = __int_as_float((raw.lab + 1) | (flagged ? kJointFlagBit : 0));
     if (live && !flagged) cm = sc * fast_exp2(cf.x);
+    pbv = cf.y;
     w.coef[((size_t)b * jg.maxT + t) * jg.maxU1 + u] = cf;
   }
+  // the 32 positions of a frame in this block are one half wavefront: their blank terms, summed
+  const float pbsum = group_sum<32>(pbv);
+  if (uu == 0) w.rowpart[((size_t)b * w.Tp + t) * ub + (u0 >> 5)] = pbsum;
   const size_t per_b = (size_t)w.Tp * w.U1p;
   w.Ctu[b * per_b + tiled_off(t, u, w.U1p >> 3)] = cm;
   tile[tt][uu] = cm;
@@ -1493,14 +1528,28 @@ __device__ __forceinline__ float fvec_get<1>(const float& v, int) { return v; }
 //   E   is the tiled matrix multiplied in element-wise at the end (`e_base`, rows m): F for d f, G for d g.
 // Lane l of MFMA tile j owns column n0 + NT*(l%32) + j, so that one load of NT consecutive floats feeds all NT
 // tiles and the results leave as NT consecutive floats.
-template <int NT>
+// What the epilogue of d f subtracts: d f(t, y) -= sum over the positions u whose next label is y of s*pl(t,u),
+// d f(t, blank) -= sum_u s*pb(t,u).  Positions that share a target are linked into a chain (k_joint_labelmap);
+// the lane that owns column y walks it in order -- no atomics, no second pass over d f.
+struct DfCorr {
+  const int* head;       // [Vp] of this utterance
+  const int* nxt;        // [maxU1 + 2]
+  const float4* coef;    // [maxT][maxU1] of this utterance
+  const float* rowpart;  // [Tp][nub]
+  int maxU1, nub, blank_pos;  // blank_pos = U_b + 1: the chain entry that stands for the blank
+};
+
+template <int NT, bool CORR>
 __device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, int a_chunks, int kmax,
                                               const float* __restrict__ b_base, const float* __restrict__ e_base,
                                               int Vp, int m0, int n0, int m_real, int V, float* __restrict__ out,
-                                              bool vec_ok, int lane) {
+                                              bool vec_ok, int lane, const DfCorr& dc) {
   typedef typename FVec<NT>::type vecn;
   const int l32 = lane & 31, h = lane >> 5, chunks = Vp >> 3;
   const int col = n0 + NT * l32;
+  int hd[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) hd[j] = CORR ? dc.head[col + j] : -1;  // col + j < Vp
   const float* ap = a_base + tiled_off(m0 + l32, 4 * h, a_chunks);
   const float* bp = b_base + tiled_off(4 * h, col, chunks);  // + 8 floats per row, + 256*chunks per 32 rows
   f16v acc[NT];
@@ -1547,29 +1596,85 @@ __device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, 
   for (int r = 0; r < 16; ++r)
     e[r] = *reinterpret_cast<const vecn*>(e_base + tiled_off(min(m0 + mm_row(r, lane), m_real - 1), col, chunks));
 #pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] *= fvec_get<NT>(e[r], j);
+  if (CORR) {
+    // The chain of positions whose target is this lane's column: its first kChain entries are fetched for all 16
+    // rows at once (independent loads, other lanes re-read entry 0 and discard it); longer chains, which need
+    // more than kChain repeats of one symbol, take the serial loop.
+    constexpr int kChain = 2;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      int k = hd[j];
+#pragma unroll
+      for (int i = 0; i < kChain; ++i) {
+        const int kc = k;
+        k = kc >= 0 ? dc.nxt[kc] : -1;
+        if (__ballot(kc >= 0) == 0ull) continue;  // uniform
+        const bool is_blank = kc == dc.blank_pos;
+        const bool is_label = kc >= 0 && !is_blank;
+        if (__ballot(is_label) != 0ull) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = min(m0 + mm_row(r, lane), m_real - 1);
+            const float x = dc.coef[(size_t)m * dc.maxU1 + (is_label ? kc : 0)].z;
+            acc[j][r] -= is_label ? x : 0.f;
+          }
+        }
+        if (__ballot(is_blank) != 0ull) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = min(m0 + mm_row(r, lane), m_real - 1);
+            float rs = 0.f;
+            for (int q = 0; q < dc.nub; ++q) rs += dc.rowpart[(size_t)m * dc.nub + q];
+            acc[j][r] -= is_blank ? rs : 0.f;
+          }
+        }
+      }
+      if (__ballot(k >= 0) != 0ull) {  // rare
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = min(m0 + mm_row(r, lane), m_real - 1);
+          float corr = 0.f;
+          for (int kk = k; kk >= 0; kk = dc.nxt[kk]) {
+            if (kk == dc.blank_pos) {
+              for (int q = 0; q < dc.nub; ++q) corr += dc.rowpart[(size_t)m * dc.nub + q];
+            } else {
+              corr += dc.coef[(size_t)m * dc.maxU1 + kk].z;
+            }
+          }
+          acc[j][r] -= corr;
+        }
+      }
+    }
+  }
+#pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + mm_row(r, lane);
     float* o = out + (size_t)m * V + col;
     if (m < m_real) {
       if (vec_ok && col + NT <= V) {
         vecn res;
-        if constexpr (NT == 1) res = e[r] * acc[0][r];
+        if constexpr (NT == 1) res = acc[0][r];
         else {
 #pragma unroll
-          for (int j = 0; j < NT; ++j) res[j] = e[r][j] * acc[j][r];
+          for (int j = 0; j < NT; ++j) res[j] = acc[j][r];
         }
         *reinterpret_cast<vecn*>(o) = res;
       } else {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          if (col + j < V) o[j] = fvec_get<NT>(e[r], j) * acc[j][r];
+          if (col + j < V) o[j] = acc[j][r];
       }
     }
   }
 }
 
 // d f(t,v) = F(t,v) * sum_u C(t,u) G(u,v): M = frames, N = vocabulary, K = label positions.
-template <int NT>
+// CORR: the blank / label terms are subtracted in the epilogue (k_joint_labelmap has run); otherwise
+// k_joint_corr_f follows.
+template <int NT, bool CORR>
 __global__ __launch_bounds__(256) void k_joint_df_mm(float* __restrict__ df, const int32_t* __restrict__ in_len,
                                                      const int32_t* __restrict__ lab_len, JointGeom jg, Ws w,
                                                      bool vec_ok) {
@@ -1579,9 +1684,15 @@ __global__ __launch_bounds__(256) void k_joint_df_mm(float* __restrict__ df, con
   utt_dims(in_len, lab_len, mt.b, jg.maxT, jg.maxU1, T, U);
   const int kmax = (mt.m0 < T) ? (U + 8) & ~7 : 0;  // C is zero beyond column U_b and in frames >= T_b
   const size_t cb = (size_t)mt.b * w.Tp * w.U1p;
-  joint_grad_mm<NT>(w.Ctu + cb, w.U1p >> 3, kmax, w.Gp + (size_t)mt.b * w.U1p * w.Vp,
-                    w.Fp + (size_t)mt.b * w.Tp * w.Vp, w.Vp, mt.m0, mt.n0, jg.maxT, jg.V,
-                    df + (size_t)mt.b * jg.dfstride, vec_ok, threadIdx.x & 63);
+  DfCorr dc;
+  dc.head = w.head_of + (size_t)mt.b * w.Vp;
+  dc.nxt = w.nxt + (size_t)mt.b * (jg.maxU1 + 2);
+  dc.coef = w.coef + (size_t)mt.b * jg.maxT * jg.maxU1;
+  dc.rowpart = w.rowpart + (size_t)mt.b * w.Tp * (w.U1p >> 5);
+  dc.maxU1 = jg.maxU1; dc.nub = w.U1p >> 5; dc.blank_pos = U + 1;
+  joint_grad_mm<NT, CORR>(w.Ctu + cb, w.U1p >> 3, kmax, w.Gp + (size_t)mt.b * w.U1p * w.Vp,
+                          w.Fp + (size_t)mt.b * w.Tp * w.Vp, w.Vp, mt.m0, mt.n0, jg.maxT, jg.V,
+                          df + (size_t)mt.b * jg.dfstride, vec_ok, threadIdx.x & 63, dc);
 }
 
 // d g(u,v) = G(u,v) * sum_t C(t,u) F(t,v): M = label positions, N = vocabulary, K = frames.
@@ -1595,12 +1706,13 @@ __global__ __launch_bounds__(256) void k_joint_dg_mm(float* __restrict__ dg, con
   utt_dims(in_len, lab_len, mt.b, jg.maxT, jg.maxU1, T, U);
   const int kmax = (mt.m0 <= U) ? (T + 7) & ~7 : 0;  // C is zero in frames >= T_b and columns > U_b
   const size_t cb = (size_t)mt.b * w.Tp * w.U1p;
-  joint_grad_mm<NT>(w.Cut + cb, w.Tp >> 3, kmax, w.Fp + (size_t)mt.b * w.Tp * w.Vp,
-                    w.Gp + (size_t)mt.b * w.U1p * w.Vp, w.Vp, mt.m0, mt.n0, jg.maxU1, jg.V,
-                    dg + (size_t)mt.b * jg.maxU1 * jg.V, vec_ok, threadIdx.x & 63);
+  joint_grad_mm<NT, false>(w.Cut + cb, w.Tp >> 3, kmax, w.Fp + (size_t)mt.b * w.Tp * w.Vp,
+                           w.Gp + (size_t)mt.b * w.U1p * w.Vp, w.Vp, mt.m0, mt.n0, jg.maxU1, jg.V,
+                           dg + (size_t)mt.b * jg.maxU1 * jg.V, vec_ok, threadIdx.x & 63, DfCorr{});
 }
 
-// Blank and label terms of d f.  d f(t, y) -= sum over the positions u whose next label is y of s*pl(t,u), and
+// Blank and label terms of d f as a pass of their own (small vocabularies, where labels repeat so often that the
+// chains are long and d f is small).  d f(t, y) -= sum over the positions u whose next label is y of s*pl(t,u), and
 // d f(t, blank) -= sum_u s*pb(t,u).  One block per (utterance, fb frames): it links the positions that share a
 // target (labels repeat; the blank is one more target) into chains, then one thread per (frame, first position of
 // a chain) adds the chain up in order and subtracts it once -- no atomics, fixed order.
@@ -1665,6 +1777,44 @@ __global__ __launch_bounds__(256) void k_joint_corr_f(float* __restrict__ df, co
     float sacc = 0.f;
     for (int k = u; k >= 0; k = nxt[k]) sacc += vr[k];
     df[(size_t)b * jg.dfstride + (size_t)(t0 + i) * jg.V + tgt[u]] -= sacc;
+  }
+}
+
+// One block per utterance: links the label positions that share a target symbol into chains (labels repeat; the
+// blank is one more target, standing at position U_b + 1) and records, per symbol, the first position of its
+// chain.  The epilogue of the d f contraction walks these chains.
+__global__ __launch_bounds__(256) void k_joint_labelmap(const int32_t* __restrict__ labels,
+                                                        const int32_t* __restrict__ in_len,
+                                                        const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
+  extern __shared__ int tgt[];  // [maxU1 + 2]
+  const int b = blockIdx.x;
+  int T, U;
+  utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
+  int* head = w.head_of + (size_t)b * w.Vp;
+  int* nxt = w.nxt + (size_t)b * (jg.maxU1 + 2);
+  for (int v = threadIdx.x; v < w.Vp; v += 256) head[v] = -1;
+  // targets: label of position u < U (clamped like everywhere else), nothing at u = U, the blank at index U+1
+  for (int u = threadIdx.x; u <= U + 1; u += 256) {
+    int y = -1;
+    if (u < U) {
+      y = labels[(size_t)b * (jg.maxU1 - 1) + u];
+      if (y < 0 || y >= jg.V) y = 0;
+    } else if (u == U + 1) {
+      y = jg.blank;
+    }
+    tgt[u] = y;
+  }
+  __syncthreads();
+  for (int u = threadIdx.x; u <= U + 1; u += 256) {
+    const int y = tgt[u];
+    int nx = -1;
+    bool first = y >= 0;
+    if (y >= 0) {
+      for (int k = U + 1; k > u; --k) nx = (tgt[k] == y) ? k : nx;
+      for (int k = 0; k < u; ++k) first = first && tgt[k] != y;
+    }
+    nxt[u] = nx;
+    if (first) head[y] = u;
   }
 }
 
@@ -2155,8 +2305,17 @@ int launch_joint_forward(const JointCall& c, float* costs, hipStream_t st) {
   const int groups = jg.B * ((w.Tp + w.U1p) / 4);
   const bool rows16 = jg.V % 4 == 0 && jg.fstride % 4 == 0 && reinterpret_cast<uintptr_t>(c.f) % 16 == 0 &&
                       reinterpret_cast<uintptr_t>(c.g) % 16 == 0;
-  if (rows16) k_joint_prep<true><<<(groups + 3) / 4, 256, 0, st>>>(c.f, c.g, jg, w);
-  else k_joint_prep<false><<<(groups + 3) / 4, 256, 0, st>>>(c.f, c.g, jg, w);
+  const unsigned pgrid = (unsigned)((groups + 3) / 4);
+#define JOINT_PREP(NIT)                                                            \
+  do {                                                                             \
+    if (rows16) k_joint_prep<true, NIT><<<pgrid, 256, 0, st>>>(c.f, c.g, jg, w);   \
+    else k_joint_prep<false, NIT><<<pgrid, 256, 0, st>>>(c.f, c.g, jg, w);         \
+  } while (0)
+  if (w.Vp <= 256) JOINT_PREP(4);
+  else if (w.Vp <= 1024) JOINT_PREP(16);
+  else if (w.Vp <= 2048) JOINT_PREP(32);
+  else JOINT_PREP(0);
+#undef JOINT_PREP
   const long long ncell = (long long)jg.B * jg.maxT * jg.maxU1;
   k_joint_gather<<<(unsigned)((ncell + 255) / 256), 256, 0, st>>>(c.f, c.g, c.labels, c.in_len, c.lab_len, jg, w);
   const int mt = w.Tp / 32;
@@ -2175,6 +2334,11 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
   const JointGeom& jg = c.jg;
   const Ws& w = c.w;
   const int ke = joint_ke(jg.V);
+  // Large vocabularies: few repeats per symbol, a big d f -> the blank / label terms go into the epilogue of the
+  // d f contraction.  Small ones (the 40 / 62-symbol sets): long chains, a small d f -> a pass of their own.
+  const bool fold = w.Vp >= 256;
+  if (fold)
+    k_joint_labelmap<<<jg.B, 256, sizeof(int) * (size_t)(jg.maxU1 + 2), st>>>(c.labels, c.in_len, c.lab_len, jg, w);
   k_joint_coef<<<(unsigned)(jg.B * (w.Tp / 8) * (w.U1p / 32)), 256, 0, st>>>(c.labels, c.in_len, c.lab_len, grad_scale,
                                                                              jg, w);
   const int mt = w.Tp / 32, mu = w.U1p / 32;
@@ -2186,18 +2350,21 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
   const bool vf = aligned(df, jg.dfstride), vg = aligned(dg, (size_t)nt);
   const int ns = w.Vp / (32 * nt);
   if (nt == 1) {
-    k_joint_df_mm<1><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
+    k_joint_df_mm<1, false><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
     k_joint_dg_mm<1><<<mm_blocks(jg.B, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
   } else if (nt == 2) {
-    k_joint_df_mm<2><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
+    k_joint_df_mm<2, false><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
     k_joint_dg_mm<2><<<mm_blocks(jg.B, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
   } else {
-    k_joint_df_mm<4><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
+    if (fold) k_joint_df_mm<4, true><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
+    else k_joint_df_mm<4, false><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
     k_joint_dg_mm<4><<<mm_blocks(jg.B, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
   }
-  const int fb = jg.maxU1 <= 128 ? 32 : jg.maxU1 <= 256 ? 16 : 8;  // frames per block: (3 + fb) * (maxU1 + 1) words of LDS
-  const size_t corr_lds = sizeof(int) * (3 + fb) * (size_t)(jg.maxU1 + 1);
-  k_joint_corr_f<<<jg.B * ((jg.maxT + fb - 1) / fb), 256, corr_lds, st>>>(df, c.labels, c.in_len, c.lab_len, jg, w, fb);
+  if (!fold) {
+    const int fb = jg.maxU1 <= 128 ? 32 : jg.maxU1 <= 256 ? 16 : 8;  // frames per block: (3 + fb) * (maxU1 + 1) words of LDS
+    const size_t corr_lds = sizeof(int) * (3 + fb) * (size_t)(jg.maxU1 + 1);
+    k_joint_corr_f<<<jg.B * ((jg.maxT + fb - 1) / fb), 256, corr_lds, st>>>(df, c.labels, c.in_len, c.lab_len, jg, w, fb);
+  }
   k_joint_corr_g<<<jg.B * ((jg.maxU1 + 63) / 64), 1024, 0, st>>>(dg, c.labels, c.in_len, c.lab_len, jg, w);
 #define JGRID_T(TT) dim3((unsigned)(jg.B * ((((jg.maxT + (TT)-1) / (TT)) + 3) / 4)))
 #define JGRID_U(UU) dim3((unsigned)(jg.B * ((((jg.maxU1 + (UU)-1) / (UU)) + 3) / 4)))
