@@ -422,7 +422,13 @@ __global__ __launch_bounds__(kRowBlock) void k_lse(const float* __restrict__ x, 
 // (add, shift, subtract, exp2, log2, add), not issue slots: splitting the
 // columns of a direction over two wavefronts (one column per lane, boundary
 // value through LDS two diagonals ahead, one s_barrier per diagonal) measured
-// 2.5x slower, 207 us against 83 us at T=400, U=100.
+// 2.5x slower, 207 us against 83 us at T=400, U=100.  Carrying alpha and beta
+// in the linear domain as (float64 mantissa, int32 exponent) pairs -- multiply,
+// ldexp, add, frexp instead of exp2/log2 on the chain -- gave the same results
+// and was also slower (one column per lane 77 us against 61 us, two columns
+// 135 us against 76 us at T=500): the float64 ldexp/frexp steps cost more than
+// the transcendentals they replace.  Measured per diagonal: 109 ns with one
+// column per lane, 127 ns with two, 230 ns with four, 494 ns with eight.
 // ---------------------------------------------------------------------------
 // lane i receives lane i-1's value; lane 0 receives `fill`
 __device__ __forceinline__ double lane_shift_up(double v, double fill) {
