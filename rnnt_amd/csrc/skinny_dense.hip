@@ -63,7 +63,7 @@ __device__ __forceinline__ void loadn(const float* p, int col, int ncol, bool ro
 // W[n][k] (TRANS = true: the data gradient multiplies by W^T).  Kd = contraction length, Nd = output columns.
 // LDS: W zero-padded to [Kp][Np + 4].  Lane l of MFMA tile j owns output column NT*(l%32) + j.
 template <int NT, int AVEC, bool DACT, bool TRANS>
-__global__ __launch_bounds__(kBlock) void k_dense_fwd(const float* __restrict__ a, const float* __restrict__ z,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_dense_fwd(const float* __restrict__ a, const float* __restrict__ z,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       float* __restrict__ y, long long M, int Kd, int Nd, int act,
                                                       bool yvec_ok) {
