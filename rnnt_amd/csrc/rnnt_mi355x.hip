@@ -621,7 +621,7 @@ struct GradTile {
 };
 
 template <int VEC, int L, int NC, int G>
-__global__ __launch_bounds__(kRowBlock) void k_grad(const float* x, float* grad, const int32_t* __restrict__ labels,
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(8))) void k_grad(const float* x, float* grad, const int32_t* __restrict__ labels,
                                                     const int32_t* __restrict__ in_len,
                                                     const int32_t* __restrict__ lab_len,
                                                     const float* __restrict__ grad_scale, RowGeom gm, Ws w) {
