@@ -51,7 +51,52 @@ def make_case(name, B, T, U, V, blank, ragged, scale, seed):
                         lab_len=lab_len, blank=np.int32(blank), grad_scale=grad_scale, costs=costs, grad=grad)
 
 
+def make_op_fixtures():
+    """Fixtures of the callers either side of the loss: the additive-joint lambda, the FC-joint loss head and
+    the decoder's inner step (tests/golden/ops/)."""
+    ops = os.path.join(HERE, "ops")
+    os.makedirs(ops, exist_ok=True)
+    rng = np.random.default_rng(777)
+    # Util.rnnt_lambda_func: y_trans [B,T0,V], y_pred [B,U+1,V], lengths [B,1], blank 39, crop of 2 frames
+    B, T0, U, V = 3, 12, 5, 62
+    yt = rng.standard_normal((B, T0, V)).astype(np.float32)
+    yp = rng.standard_normal((B, U + 1, V)).astype(np.float32)
+    lab = rng.integers(0, 39, (B, U)).astype(np.int32)
+    il = np.array([[12], [9], [11]], np.int32)
+    ll = np.array([[5], [3], [4]], np.int32)
+    gs = np.full(B, 1.0 / B)
+    costs, dt, dp = orc.rnnt_lambda_func(yt, yp, lab, il, ll, blank_label=39, grad_scale=gs)
+    np.savez_compressed(os.path.join(ops, "lambda_additive_joint.npz"), y_trans=yt, y_pred=yp, labels=lab,
+                        input_length=il, label_length=ll, grad_scale=gs, costs=costs, d_trans=dt, d_pred=dp)
+    # FC-joint loss head: concatenate_lambda -> Dense(tanh) -> Dense -> rnnt_lambda_func_v2
+    He, Hd, H = 10, 6, 8
+    yt2 = (rng.standard_normal((B, T0, He)) * 0.5).astype(np.float32)
+    yp2 = (rng.standard_normal((B, U + 1, Hd)) * 0.5).astype(np.float32)
+    k1 = rng.uniform(-0.5, 0.5, (He + Hd, H)).astype(np.float32)
+    b1 = rng.uniform(-0.1, 0.1, H).astype(np.float32)
+    k2 = rng.uniform(-0.5, 0.5, (H, V)).astype(np.float32)
+    b2 = rng.uniform(-0.1, 0.1, V).astype(np.float32)
+    c2, d_t, d_p, dws = orc.fc_joint_loss_and_grads(yt2, yp2, [(k1, b1), (k2, b2)], lab, il, ll, blank_label=39,
+                                                    grad_scale=gs)
+    np.savez_compressed(os.path.join(ops, "fc_joint_two_layers.npz"), y_trans=yt2, y_pred=yp2, k1=k1, b1=b1, k2=k2,
+                        b2=b2, labels=lab, input_length=il, label_length=ll, grad_scale=gs, costs=c2, d_trans=d_t,
+                        d_pred=d_p, dk1=dws[0][0], db1=dws[0][1], dk2=dws[1][0], db2=dws[1][1])
+    # decoder inner step for a small beam
+    enc = (rng.standard_normal((4, V)) * 3).astype(np.float32)
+    pred = (rng.standard_normal((6, V)) * 3).astype(np.float32)
+    fi = np.array([0, 0, 1, 1, 2, 3, 3, 3, 2], np.int32)
+    gi = np.array([0, 1, 0, 5, 2, 3, 4, 0, 5], np.int32)
+    logp = np.stack([orc.decoder_step_logp(enc[i], pred[j]) for i, j in zip(fi, gi)])
+    np.savez_compressed(os.path.join(ops, "decoder_step.npz"), enc=enc, pred=pred, enc_index=fi, pred_index=gi, logp=logp)
+    # the second public known-answer vector, published values
+    x, lab2, il2, ll2, blank2, pc, pg = orc.known_answer_batch()
+    np.savez_compressed(os.path.join(ops, "known_answer_batch.npz"), logits=x.astype(np.float32), labels=lab2,
+                        in_len=il2, lab_len=ll2, blank=np.int32(blank2), published_costs=pc, published_grad=pg)
+    print("wrote 4 fixtures to", ops)
+
+
 def main():
+    make_op_fixtures()
     for k, c in enumerate(CASES):
         make_case(*c, seed=20240 + k)
     K = orc.KNOWN_ANSWER

@@ -193,3 +193,27 @@ def test_util_softmax_restatement():
     for r, row in zip(rows, m):
         np.testing.assert_allclose(r, np.exp(row) / np.exp(row).sum(), atol=1e-12)
     np.testing.assert_allclose(orc.decoder_step_logp(x, x[::-1]), orc.log_softmax((x + x[::-1])[None])[0], atol=1e-12)
+
+
+def test_op_fixtures_are_reproduced(golden_dir):
+    """tests/golden/ops/*.npz: the lambdas, the FC-joint loss head, the decoder step, the second public vector."""
+    ops = os.path.join(golden_dir, "ops")
+    z = np.load(os.path.join(ops, "lambda_additive_joint.npz"))
+    c, dt, dp = orc.rnnt_lambda_func(z["y_trans"], z["y_pred"], z["labels"], z["input_length"], z["label_length"],
+                                     blank_label=39, grad_scale=z["grad_scale"])
+    np.testing.assert_allclose(c, z["costs"], rtol=1e-12)
+    np.testing.assert_allclose(dt, z["d_trans"], atol=1e-12)
+    np.testing.assert_allclose(dp, z["d_pred"], atol=1e-12)
+    z = np.load(os.path.join(ops, "fc_joint_two_layers.npz"))
+    c, dt, dp, dws = orc.fc_joint_loss_and_grads(z["y_trans"], z["y_pred"], [(z["k1"], z["b1"]), (z["k2"], z["b2"])],
+                                                 z["labels"], z["input_length"], z["label_length"], blank_label=39,
+                                                 grad_scale=z["grad_scale"])
+    np.testing.assert_allclose(c, z["costs"], rtol=1e-12)
+    np.testing.assert_allclose(dws[1][0], z["dk2"], atol=1e-12)
+    z = np.load(os.path.join(ops, "decoder_step.npz"))
+    for n, (i, j) in enumerate(zip(z["enc_index"], z["pred_index"])):
+        np.testing.assert_allclose(orc.decoder_step_logp(z["enc"][i], z["pred"][j]), z["logp"][n], atol=1e-12)
+    z = np.load(os.path.join(ops, "known_answer_batch.npz"))
+    c, g = orc.rnnt_loss_and_grad(z["logits"], z["labels"], z["in_len"], z["lab_len"], int(z["blank"]))
+    np.testing.assert_allclose(c, z["published_costs"], rtol=2e-7)
+    np.testing.assert_allclose(g, z["published_grad"], atol=1e-6)
