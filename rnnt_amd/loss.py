@@ -43,7 +43,8 @@ def _prepare(acts, labels, input_lengths, label_lengths, blank_label):
 
 
 def _prepare_meta(B, T, U1, V, dev, labels, input_lengths, label_lengths, blank_label):
-    labels = torch.as_tensor(labels).to(device=dev, dtype=torch.int32).reshape(B, -1)
+    labels_in = torch.as_tensor(labels)
+    labels = labels_in.to(device=dev, dtype=torch.int32).reshape(B, -1)
     if labels.shape[1] != U1 - 1:
         raise ValueError(f"labels must be [B, U] with U = acts.shape[2]-1 = {U1 - 1}, got {tuple(labels.shape)}")
     labels = labels.contiguous()
@@ -51,17 +52,25 @@ def _prepare_meta(B, T, U1, V, dev, labels, input_lengths, label_lengths, blank_
     ll = torch.as_tensor(label_lengths)
     if il.numel() != B or ll.numel() != B:
         raise ValueError("input_lengths and label_lengths must hold B elements")
-    # host-side validation is free when the lengths are host tensors
+    # host-side validation is free when the lengths (and labels) are host tensors; what has been checked here
+    # need not be read back from the device after the forward (fifth return value)
+    host_ok = False
     if not il.is_cuda and not ll.is_cuda:
         ilh, llh = il.reshape(B).long(), ll.reshape(B).long()
         if bool(((ilh < 1) | (ilh > T)).any()) or bool(((llh < 0) | (llh > U1 - 1)).any()):
             raise ValueError("input_lengths must lie in [1, T] and label_lengths in [0, U]")
+        if not labels_in.is_cuda:
+            lab_h = labels_in.reshape(B, -1).long()
+            used = torch.arange(U1 - 1).unsqueeze(0) < llh.unsqueeze(1)
+            if bool((((lab_h < 0) | (lab_h >= V)) & used).any()):
+                raise ValueError("rnnt_loss: a label is outside [0, V)")
+            host_ok = True
     il = il.to(device=dev, dtype=torch.int32).reshape(B).contiguous()
     ll = ll.to(device=dev, dtype=torch.int32).reshape(B).contiguous()
     blank_label = int(blank_label)
     if not 0 <= blank_label < V:
         raise ValueError(f"blank_label {blank_label} outside [0, {V})")
-    return labels, il, ll, blank_label
+    return labels, il, ll, blank_label, host_ok
 
 
 def _workspace(B, T, U1, device):
@@ -164,18 +173,20 @@ def rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0, *, inpl
     (util.py:62-64).  The gradient of the skipped frames is zero.
     inplace=True lets backward overwrite ``acts`` with its gradient (saves a
     [B,T,U+1,V] allocation); only legal when nothing else reads ``acts`` later.
-    check_inputs=True reads a 4-byte validation word back after the forward
-    (one stream sync) and raises ValueError on malformed lengths/labels.
+    check_inputs=True raises ValueError on malformed lengths/labels: lengths
+    and labels given as host tensors are checked on the host; otherwise a 4-byte
+    validation word is read back after the forward (one stream sync).
     """
     t_offset = int(t_offset)
     if not isinstance(acts, torch.Tensor) or acts.dim() != 4 or not 0 <= t_offset < acts.shape[1]:
         raise ValueError("acts must be a [B, T, U+1, V] tensor and 0 <= t_offset < T")
     cropped = acts[:, t_offset:]
-    labels, il, ll, blank = _prepare(cropped, labels, input_lengths, label_lengths, blank_label)
+    labels, il, ll, blank, host_ok = _prepare(cropped, labels, input_lengths, label_lengths, blank_label)
     if not _batch_strided(acts):
         acts = acts.contiguous()  # a differentiable copy that nobody else reads: backward may overwrite it
         inplace = True
-    return _RNNTLossFn.apply(acts, labels, il, ll, blank, bool(inplace), bool(check_inputs), t_offset)
+    # what the host has already validated needs no read-back (and no stream sync) after the forward
+    return _RNNTLossFn.apply(acts, labels, il, ll, blank, bool(inplace), bool(check_inputs) and not host_ok, t_offset)
 
 
 class _RNNTJointLossFn(torch.autograd.Function):
@@ -247,9 +258,10 @@ def rnnt_joint_loss(f, g, labels, input_lengths, label_lengths, blank_label=0, *
     U1 = g.shape[1]
     if V > 4096:
         raise ValueError("rnnt_joint_loss supports V <= 4096")
-    labels, il, ll, blank = _prepare_meta(B, T0 - t_offset, U1, V, f.device, labels, input_lengths, label_lengths,
-                                          blank_label)
-    return _RNNTJointLossFn.apply(f.contiguous(), g.contiguous(), labels, il, ll, blank, bool(check_inputs), t_offset)
+    labels, il, ll, blank, host_ok = _prepare_meta(B, T0 - t_offset, U1, V, f.device, labels, input_lengths,
+                                                   label_lengths, blank_label)
+    return _RNNTJointLossFn.apply(f.contiguous(), g.contiguous(), labels, il, ll, blank,
+                                  bool(check_inputs) and not host_ok, t_offset)
 
 
 def rnnt_loss_grad_(acts, labels, input_lengths, label_lengths, blank_label=0, grad_scale=None, *, workspace=None,
@@ -257,7 +269,8 @@ def rnnt_loss_grad_(acts, labels, input_lengths, label_lengths, blank_label=0, g
     """Fused forward+backward without autograd: returns costs ``[B]`` and
     overwrites ``acts`` with d(sum_b grad_scale[b]*cost_b)/d(acts).  This is the
     call bench.py times (one rnnt_mi355x_loss_grad)."""
-    labels, il, ll, blank = _prepare(acts, labels, input_lengths, label_lengths, blank_label)
+    labels, il, ll, blank, host_ok = _prepare(acts, labels, input_lengths, label_lengths, blank_label)
+    check_inputs = check_inputs and not host_ok
     if not acts.is_contiguous():
         raise ValueError("rnnt_loss_grad_ needs contiguous acts (it writes the gradient in place)")
     B, T, U1, V = acts.shape
