@@ -290,7 +290,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"config {args.config}: {cfg['name']}, fp32 logits ~ N(0,1), blank={blank}, "
+            "workload": f"config {args.config}: {cfg['name']}{' (B overridden to %d)' % B if args.batch else ''}, "
+                        f"fp32 logits ~ N(0,1), blank={blank}, "
                         f"grad_scale=1/B, per-GPU batch (weak scaling: global batch = {B}*n_gpus)",
             "cells_per_gpu": cells, "logits_bytes_per_gpu": nbytes, "ring_buffers": ring_n,
             "parallelism": f"utterance-sharded dp{world}, one 16-byte all-reduce per step" if world > 1 else "single GPU",
