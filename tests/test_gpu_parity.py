@@ -285,3 +285,27 @@ def test_random_shapes_fuzz():
             _check(x, lab, il, ll, blank, gs)
         except AssertionError as e:
             raise AssertionError(f"case {case}: B={B} T={T} U={U} V={V} blank={blank} scale={scale}: {e}")
+
+
+@pytest.mark.parametrize("B,T,U,V,blank", [(2, 9, 4, 40, 39), (2, 7, 3, 300, 0)])
+def test_masked_vocabulary_entries(B, T, U, V, blank):
+    """Logits of -inf (masked symbols that are neither the blank nor a needed label): probability exactly 0,
+    gradient exactly 0 there, everything else unaffected."""
+    x, lab, il, ll = make_batch(B, T, U, V, blank, seed=77)
+    rng = np.random.default_rng(5)
+    mask = rng.random(x.shape) < 0.15
+    mask[..., blank] = False
+    for b in range(B):
+        mask[b][..., lab[b]] = False
+    x = x.copy()
+    x[mask] = -np.inf
+    with np.errstate(invalid="ignore"):
+        co, go = orc.rnnt_loss_and_grad(x, lab, il, ll, blank)
+    assert np.isfinite(co).all() and np.isfinite(go).all()
+    run = HipRun(x, lab, il, ll, blank)
+    assert run.loss_grad() == 0
+    torch.cuda.synchronize()
+    g = run.x.cpu().numpy()
+    np.testing.assert_allclose(run.costs.cpu().numpy(), co, rtol=COST_RTOL)
+    assert np.isfinite(g).all() and np.abs(g - go).max() < GRAD_ATOL_TIGHT
+    assert not g[mask].any()

@@ -391,3 +391,26 @@ def test_fused_joint_with_peaked_outputs(scale):
     np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
     assert np.abs(tf_.grad.cpu().numpy() - gj.sum(2)).max() < GRAD_ATOL
     assert np.abs(tg.grad.cpu().numpy() - gj.sum(1)).max() < GRAD_ATOL
+
+
+def test_fused_joint_with_masked_vocabulary_entries():
+    B, T, U, V, blank = 2, 20, 5, 70, 69
+    rng = np.random.default_rng(91)
+    f = rng.standard_normal((B, T, V)).astype(np.float32)
+    g = rng.standard_normal((B, U + 1, V)).astype(np.float32)
+    lab = rng.integers(0, V - 1, (B, U)).astype(np.int32)
+    masked = np.setdiff1d(np.arange(V - 1), lab.reshape(-1))[:12]   # symbols no utterance needs
+    f[:, ::3, masked[:6]] = -np.inf
+    g[:, 1::2, masked[6:]] = -np.inf
+    il, ll = np.array([T, T - 3], np.int32), np.array([U, 3], np.int32)
+    with np.errstate(invalid="ignore"):
+        joint = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
+        co, gj = orc.rnnt_loss_and_grad(joint, lab, il, ll, blank)
+    tf_ = torch.from_numpy(f).to(DEV).requires_grad_(True)
+    tg = torch.from_numpy(g).to(DEV).requires_grad_(True)
+    costs = rnnt_amd.rnnt_joint_loss(tf_, tg, lab, il, ll, blank)
+    costs.sum().backward()
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+    df, dg = tf_.grad.cpu().numpy(), tg.grad.cpu().numpy()
+    assert np.isfinite(df).all() and np.isfinite(dg).all()
+    assert np.abs(df - gj.sum(2)).max() < GRAD_ATOL and np.abs(dg - gj.sum(1)).max() < GRAD_ATOL
