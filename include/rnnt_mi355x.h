@@ -33,7 +33,7 @@
  *     except rnnt_mi355x_read_status, none synchronises;
  *   - every function returns an rnnt_mi355x_status; nothing throws or aborts.
  *
- * Limits: 1 <= maxU1 <= 512, B*maxT*maxU1 < 2^31, (maxT+2)*maxU1 < 2^28,
+ * Limits: 1 <= maxU1 <= 1024, B*maxT*maxU1 < 2^31, (maxT+2)*maxU1 < 2^28,
  * V >= 1.  Element offsets into logits are 64-bit.
  */
 #ifndef RNNT_MI355X_H_

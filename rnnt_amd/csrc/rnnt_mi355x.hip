@@ -33,7 +33,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr double kLn2 = 0.6931471805599453;
 constexpr float kNegF = -1.0e30f;  // "log 0" that stays finite under addition
 constexpr double kNeg = -1.0e30;
-constexpr int kMaxU1 = 512;
+constexpr int kMaxU1 = 1024;
 constexpr int kRowBlock = 256;  // threads per block of the streaming kernels
 constexpr int kRowWaves = kRowBlock / 64;
 // Lattice cells whose occupancy gamma = exp(alpha+beta-ll) is below 2^kPruneLog2 (~9e-13) get an exactly zero
@@ -82,10 +82,12 @@ struct Ws {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Lattice columns each lane of a sweep wavefront owns (1, 2, 4 or 8).  The
+// Lattice columns each lane of a sweep wavefront owns (1, 2, 4, 8 or 16).  The
 // row stride of the per-cell arrays is 64 times this, so that every lane of a
 // sweep can load and store its columns unconditionally.
-inline int sweep_cols_per_lane(int maxU1) { return maxU1 <= 64 ? 1 : maxU1 <= 128 ? 2 : maxU1 <= 256 ? 4 : 8; }
+inline int sweep_cols_per_lane(int maxU1) {
+  return maxU1 <= 64 ? 1 : maxU1 <= 128 ? 2 : maxU1 <= 256 ? 4 : maxU1 <= 512 ? 8 : 16;
+}
 
 // Lays the workspace out; returns total bytes.  base may be null (size query).
 size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = false, int V = 0) {
@@ -455,7 +457,7 @@ __device__ __forceinline__ void load_lp_diag(const float4* rec0, int d, int maxT
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const int t1 = min(max(d - ucol[i], -1), maxT) + 1;                    // frame index incl. guards (v_med3_i32)
-    // 24-bit multiply-add (full rate; t1 <= maxT + 1 < 2^24, maxU1 <= 512), 32-bit byte offset from a uniform base
+    // 24-bit multiply-add (full rate; t1 <= maxT + 1 < 2^24, maxU1 <= 1024), 32-bit byte offset from a uniform base
     const unsigned off = __umul24((unsigned)t1, (unsigned)maxU1) + (unsigned)uoff[i];  // uoff = min(u, maxU1-1) or a guard slot
     const float2 q = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rec0) + (size_t)(off << 4));
     pb[i] = q.x;
@@ -2180,7 +2182,8 @@ void launch_sweep(const Call& c, int b0, int nb, hipStream_t st) {
     case 1: k_sweep<1><<<grid, 64, 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0); break;
     case 2: k_sweep<2><<<grid, 64, 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0); break;
     case 4: k_sweep<4><<<grid, 64, 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0); break;
-    default: k_sweep<8><<<grid, 64, 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0); break;
+    case 8: k_sweep<8><<<grid, 64, 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0); break;
+    default: k_sweep<16><<<grid, 64, 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0); break;
   }
 }
 

@@ -43,8 +43,9 @@ def test_workspace_query_and_shape_validation():
     out = ctypes.c_size_t(0)
     f = _lib.lib().rnnt_mi355x_workspace_bytes
     assert f(0, 10, 10, ctypes.byref(out)) == _lib.INVALID_VALUE
-    assert f(1, 10, 513, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE
+    assert f(1, 10, 1025, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE
     assert f(1 << 12, 1 << 10, 512, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE  # B*T*U1 >= 2^31
+    assert f(1, 1 << 19, 1024, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE         # (maxT+2)*maxU1 >= 2^28
     assert f(1, 10, 10, None) == _lib.INVALID_VALUE
 
 
@@ -55,7 +56,7 @@ def test_null_and_range_arguments_are_rejected_before_any_launch():
     assert L.rnnt_mi355x_forward(one, one, one, one, 1, 2, 2, 4, 4, one, one, None) == _lib.INVALID_VALUE
     assert L.rnnt_mi355x_forward(one, one, one, one, 1, 2, 2, 4, -1, one, one, None) == _lib.INVALID_VALUE
     assert L.rnnt_mi355x_backward(one, None, one, one, one, 1, 2, 2, 4, 0, None, one, None) == _lib.INVALID_VALUE
-    assert L.rnnt_mi355x_loss_grad(one, one, one, one, 1, 2, 600, 4, 0, None, one, one, None) == _lib.UNSUPPORTED_SIZE
+    assert L.rnnt_mi355x_loss_grad(one, one, one, one, 1, 2, 1100, 4, 0, None, one, one, None) == _lib.UNSUPPORTED_SIZE
     assert L.rnnt_mi355x_reduce_scalars(None, 1, one, one, None) == _lib.INVALID_VALUE
 
 

@@ -76,7 +76,7 @@ def test_golden_fixtures(golden_dir):
 
 
 # (B, T, U, V, blank): covers every (VEC, lanes-per-row, chunks) instantiation of the row kernels
-# and every columns-per-lane variant of the sweep (U+1 <= 64, 128, 256, 512).
+# and every columns-per-lane variant of the sweep (U+1 <= 64, 128, 256, 512, 1024).
 SHAPES = [
     (3, 9, 5, 5, 0),        # VEC1 L8
     (2, 8, 4, 13, 12),      # VEC1 L16
@@ -101,7 +101,9 @@ SHAPES = [
     (2, 30, 70, 12, 11),    # sweep K=2
     (2, 20, 150, 8, 0),     # sweep K=4
     (1, 12, 300, 4, 3),     # sweep K=8
-    (1, 5, 511, 4, 0),      # maximum supported U+1 = 512
+    (1, 5, 511, 4, 0),      # U+1 = 512: eight columns per lane
+    (1, 4, 700, 5, 2),      # sixteen columns per lane
+    (1, 3, 1023, 3, 0),     # maximum supported U+1 = 1024
     (2, 1, 6, 10, 9),       # T = 1
     (2, 9, 0, 10, 2),       # U = 0 (no labels; labels pointer unused)
     (1, 1, 0, 3, 1),        # single cell

@@ -187,6 +187,7 @@ JOINT_SHAPES = [  # B, T, U, V, blank -> every elements-per-lane variant of the 
     (2, 6, 0, 30, 2), (1, 20, 130, 16, 15),
     # several 32-row tiles / column strips of the contractions, ragged edges in every dimension
     (2, 70, 40, 150, 149), (1, 45, 70, 33, 0), (2, 33, 64, 129, 64), (1, 100, 12, 300, 17),
+    (1, 6, 600, 9, 8),   # more than 512 label positions
 ]
 
 
