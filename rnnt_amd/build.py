@@ -13,6 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = [os.path.join(CSRC, "rnnt_mi355x.hip"), os.path.join(CSRC, "fc_joint.hip"),
            os.path.join(CSRC, "skinny_dense.hip"), os.path.join(CSRC, "decode_step.hip")]
+# rnnt_mi355x.hip is one translation unit whose kernels live in these included pieces
+PIECES = [os.path.join(CSRC, n) for n in ("workspace.h", "device_util.h", "lse_rows.h", "sweep.h", "grad_rows.h",
+                                          "small_vocab.h", "joint.h", "aux_kernels.h")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rnnt_mi355x.h")
 LIB = os.path.join(CSRC, "librnnt_mi355x.so")
 
@@ -28,7 +31,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in (*SOURCES, HEADER))
+    return any(os.path.getmtime(p) > t for p in (*SOURCES, *PIECES, HEADER))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -1,0 +1,55 @@
+// Part of the single translation unit rnnt_mi355x.hip: small kernels: zero-fill of cropped frames, workspace init, batch scalars.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "workspace.h"
+
+namespace {
+
+// zeroes the first n floats of every utterance (the frames a crop along T leaves out of the lattice)
+__global__ __launch_bounds__(256) void k_zero_frames(float* __restrict__ g, size_t batch_stride, size_t n) {
+  float* p = g + (size_t)blockIdx.y * batch_stride;
+  const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (i0 + k < n) p[i0 + k] = 0.f;
+}
+
+__global__ __launch_bounds__(64) void k_init(Ws w, int n_partial) {
+  if (threadIdx.x == 0) {
+    w.hdr->flags = 0;
+    w.hdr->n_fallback = 0;
+    w.hdr->n_partial = n_partial;
+    w.hdr->partial_off = w.partial_off;
+  }
+}
+
+// out2[0] = sum costs, out2[1] = sum of the per-block partials of the last k_grad.
+__global__ __launch_bounds__(1024) void k_reduce_scalars(const float* __restrict__ costs, int B, const char* ws_base,
+                                                         double* __restrict__ out2) {
+  __shared__ double sh[2][1024];
+  const Header* hdr = reinterpret_cast<const Header*>(ws_base);
+  const float* partial = reinterpret_cast<const float*>(ws_base + hdr->partial_off);
+  const int n = hdr->n_partial;
+  double c = 0.0, s = 0.0;
+  for (int i = threadIdx.x; i < B; i += 1024) c += (double)costs[i];
+  for (int i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
+  sh[0][threadIdx.x] = c;
+  sh[1][threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = sh[0][0];
+    out2[1] = sh[1][0];
+  }
+}
+
+}  // namespace

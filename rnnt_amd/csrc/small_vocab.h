@@ -1,0 +1,398 @@
+// Part of the single translation unit rnnt_mi355x.hip: the small-vocabulary (V <= 64) variants of the two streaming passes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "workspace.h"
+#include "device_util.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Small-vocabulary variants (V <= 64: the phone-level vocabularies the
+// reference trains on, V = 40 / 62).  A row is only V*4 <= 256 bytes, so
+// splitting it over lanes spends more on cross-lane reductions than on the
+// row itself.  Instead a wavefront streams tiles of 64 consecutive rows
+// (16*V float4, coalesced) through registers into LDS and then every LANE
+// owns one ROW: max, sum of exponentials and the gradient are plain serial
+// loops over LDS with no cross-lane traffic at all, and the 64 records of a
+// tile leave as one contiguous 1 KiB store.  The next tile's loads are in
+// flight while the current one is processed.
+// ---------------------------------------------------------------------------
+constexpr int kSmallMaxV = 64;
+constexpr int kSmallBlock = 128;                // two wavefronts, each with its own LDS tile
+constexpr int kSmallWaves = kSmallBlock / 64;
+constexpr int kSmallNld = kSmallMaxV * 64 / 4 / 64;  // float4 loads per lane per tile (max)
+
+struct SmallGeom {
+  int B, maxT, maxU1, V, blank;
+  int frames;            // frames per utterance in memory = t_off + maxT
+  int t_off;             // leading frames of every utterance that take no part in the lattice (a crop along T)
+  int ntiles_full;       // tiles of 64 whole rows
+  long long total_rows;  // B*frames*maxU1
+};
+
+// b, T, U are in/out: the lengths are reloaded only when the lane's utterance changes (rarely), so that
+// decoding a tile does not wait on memory.
+// in_range: the row is a frame of the lattice's [maxT, maxU1] grid (inside the tensor and not a cropped frame);
+// t is then its frame index in the crop.
+__device__ __forceinline__ void small_decode(long long row, const SmallGeom& g, const int32_t* in_len,
+                                             const int32_t* lab_len, int& b, int& t, int& u, int& T, int& U,
+                                             bool& in_range) {
+  const bool in_tensor = row < g.total_rows;
+  const unsigned r = in_tensor ? (unsigned)row : 0u;
+  const unsigned per_b = (unsigned)g.frames * (unsigned)g.maxU1;
+  const int nb = (int)(r / per_b);
+  const unsigned rem = r - (unsigned)nb * per_b;
+  const int tf = (int)(rem / (unsigned)g.maxU1);
+  u = (int)(rem - (unsigned)tf * (unsigned)g.maxU1);
+  t = tf - g.t_off;
+  in_range = in_tensor & (t >= 0);
+  t = max(t, 0);
+  if (nb != b) {
+    b = nb;
+    utt_dims(in_len, lab_len, b, g.maxT, g.maxU1, T, U);
+  }
+}
+
+// log-sum-exp2 of one row held in LDS (row-per-lane); VEC = widest aligned access of a row
+template <int VEC>
+__device__ __forceinline__ float small_row_lse2(const float* rowp, int V) {
+  float m = -INFINITY;
+  for (int i = 0; i < V; i += VEC) {
+    float c[VEC];
+    if constexpr (VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(rowp + i); c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w; }
+    else if constexpr (VEC == 2) { const float2 q = *reinterpret_cast<const float2*>(rowp + i); c[0] = q.x; c[1] = q.y; }
+    else { c[0] = rowp[i]; }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) m = fmaxf(m, c[q]);
+  }
+  const float m2 = m * kLog2e;
+  float s = 0.f;
+  for (int i = 0; i < V; i += VEC) {
+    float c[VEC];
+    if constexpr (VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(rowp + i); c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w; }
+    else if constexpr (VEC == 2) { const float2 q = *reinterpret_cast<const float2*>(rowp + i); c[0] = q.x; c[1] = q.y; }
+    else { c[0] = rowp[i]; }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) s += fast_exp2(__builtin_fmaf(c[q], kLog2e, -m2));
+  }
+  return m2 + fast_log2(s);
+}
+
+// Writes the record of one row (and the guard-frame entries next to frames 0 and maxT-1).
+__device__ __forceinline__ void small_write_record(const Ws& w, const SmallGeom& g, int b, int t, int u, float4 rc) {
+  float4* frame0 = w.rec + ((size_t)b * (g.maxT + 2) + 1) * g.maxU1;
+  frame0[(size_t)t * g.maxU1 + u] = rc;
+  const float4 neg = make_float4(kNegF, kNegF, 0.f, 0.f);
+  if (t == 0) (frame0 - g.maxU1)[u] = neg;
+  if (t == g.maxT - 1) (frame0 + (size_t)g.maxT * g.maxU1)[u] = neg;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restrict__ x,
+                                                           const int32_t* __restrict__ labels,
+                                                           const int32_t* __restrict__ in_len,
+                                                           const int32_t* __restrict__ lab_len, SmallGeom g, Ws w) {
+  extern __shared__ float4 lds4[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int V = g.V;
+  const int tile_f4 = 16 * V;  // 64 rows * V floats / 4
+  float4* tile4 = lds4 + wv * tile_f4;
+  const float* rowp = reinterpret_cast<const float*>(tile4) + lane * V;
+  const int gw = blockIdx.x * kSmallWaves + wv, nw = gridDim.x * kSmallWaves;
+  const f4v* x4 = reinterpret_cast<const f4v*>(x);
+
+  int T = 0;
+  auto row_valid = [&](int n, int& b, int& t, int& u, int& U, bool& in_range) {
+    small_decode((long long)n * 64 + lane, g, in_len, lab_len, b, t, u, T, U, in_range);
+    return in_range & (t < T) & (u <= U);
+  };
+
+  f4v st[kSmallNld];
+  auto issue = [&](int n, bool any) {
+    if (!any) return;
+    const f4v* src = x4 + (size_t)n * tile_f4;
+#pragma unroll
+    for (int i = 0; i < kSmallNld; ++i) {
+      const int q = lane + 64 * i;
+      if (q < tile_f4) st[i] = __builtin_nontemporal_load(src + q);
+    }
+  };
+
+  int n = gw;
+  int b = -1, t = 0, u = 0, U = 0;
+  bool in_range = false;
+  bool valid = false, any = false;
+  if (n < g.ntiles_full) {
+    valid = row_valid(n, b, t, u, U, in_range);
+    any = __ballot(valid) != 0ull;
+    issue(n, any);
+  }
+  for (; n < g.ntiles_full; n += nw) {
+    // stage the tile into LDS (only this wavefront touches it: in-order LDS, no barrier needed)
+    if (any) {
+#pragma unroll
+      for (int i = 0; i < kSmallNld; ++i) {
+        const int q = lane + 64 * i;
+        if (q < tile_f4) tile4[q] = make_float4(st[i].x, st[i].y, st[i].z, st[i].w);
+      }
+    }
+    const int cb = b, ct = t, cu = u, cU = U;
+    const bool cvalid = valid, cany = any, cin = in_range;
+    // next tile: decode and put its loads in flight before working on this one
+    const int nn = n + nw;
+    if (nn < g.ntiles_full) {
+      valid = row_valid(nn, b, t, u, U, in_range);
+      any = __ballot(valid) != 0ull;
+      issue(nn, any);
+    }
+    float4 rc = make_float4(kNegF, kNegF, 0.f, 0.f);
+    if (cany && cvalid) {
+      const float lse2 = small_row_lse2<VEC>(rowp, V);
+      float lpl = kNegF;
+      if (cu < cU) {
+        int lab = labels[(size_t)cb * (g.maxU1 - 1) + cu];
+        if (lab < 0 || lab >= V) {
+          atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
+          lab = 0;
+        }
+        lpl = __builtin_fmaf(rowp[lab], kLog2e, -lse2);
+      }
+      rc = make_float4(__builtin_fmaf(rowp[g.blank], kLog2e, -lse2), lpl, lse2, 0.f);
+    }
+    if (cin) small_write_record(w, g, cb, ct, cu, rc);
+  }
+  // the last, partial tile (fewer than 64 rows): one wavefront reads its rows straight from global memory
+  if (gw == 0 && (long long)g.ntiles_full * 64 < g.total_rows) {
+    const long long row = (long long)g.ntiles_full * 64 + lane;
+    b = -1;
+    small_decode(row, g, in_len, lab_len, b, t, u, T, U, in_range);
+    if (in_range) {
+      float4 rc = make_float4(kNegF, kNegF, 0.f, 0.f);
+      if (t < T && u <= U) {
+        const float* rp = x + (size_t)row * V;
+        const float lse2 = small_row_lse2<1>(rp, V);
+        float lpl = kNegF;
+        if (u < U) {
+          int lab = labels[(size_t)b * (g.maxU1 - 1) + u];
+          if (lab < 0 || lab >= V) {
+            atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
+            lab = 0;
+          }
+          lpl = __builtin_fmaf(rp[lab], kLog2e, -lse2);
+        }
+        rc = make_float4(__builtin_fmaf(rp[g.blank], kLog2e, -lse2), lpl, lse2, 0.f);
+      }
+      small_write_record(w, g, b, t, u, rc);
+    }
+  }
+}
+
+// Everything the gradient of a row needs about its lattice cell, as loaded (no arithmetic yet, so that the
+// loads can be issued a tile ahead of their use).
+struct CellRaw {
+  double a, be, be_t, be_u, ll;
+  float4 rc;  // {lpb, lpl, lse, -}
+  int lab;
+  int flags;  // 1 lattice cell, 2 t < T-1, 4 u == U, 8 u < U
+};
+
+__device__ __forceinline__ CellRaw cell_load(const Ws& w, const int32_t* labels, int b, int t, int u, int T, int U,
+                                             int maxT, int maxU1, int V, bool in_range) {
+  CellRaw r;
+  r.a = r.be = r.be_t = r.be_u = r.ll = 0.0;
+  r.rc = make_float4(0.f, 0.f, 0.f, 0.f);
+  r.lab = -1;
+  r.flags = 0;
+  if (in_range && t < T && u <= U) {
+    const int U1s = w.U1s;
+    const size_t ci = ((size_t)b * w.D + (t + u)) * U1s + u;
+    r.flags = 1 | (t < T - 1 ? 2 : 0) | (u == U ? 4 : 0) | (u < U ? 8 : 0);
+    r.a = w.alpha[ci];
+    r.be = w.beta[ci];
+    r.ll = w.ll[b];
+    r.rc = w.rec[((size_t)b * (maxT + 2) + 1 + t) * maxU1 + u];
+    if (t < T - 1) r.be_t = w.beta[ci + U1s];
+    if (u < U) {
+      r.be_u = w.beta[ci + U1s + 1];
+      const int l = labels[(size_t)b * (maxU1 - 1) + u];
+      r.lab = (l < 0 || l >= V) ? 0 : l;
+    }
+  }
+  return r;
+}
+
+// {c2, pb, pl, label} of the cell (c2 = -inf: the row's gradient is exactly zero)
+__device__ __forceinline__ float4 cell_coef(const CellRaw& r) {
+  float4 cf = make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
+  if (r.flags & 1) {
+    const double a_ll = r.a - r.ll;
+    const float g2 = (float)(a_ll + r.be);  // log2 gamma
+    if (g2 >= kPruneLog2) {
+      float e_b = -INFINITY;  // 2^-inf = 0: no blank move out of this cell
+      if (r.flags & 2) e_b = (float)(a_ll + r.be_t) + r.rc.x;
+      else if (r.flags & 4) e_b = (float)a_ll + r.rc.x;
+      const float plv = (r.flags & 8) ? fast_exp2((float)(a_ll + r.be_u) + r.rc.y) : 0.f;
+      cf = make_float4(g2 - r.rc.z, fast_exp2(e_b), plv, __int_as_float(r.lab));
+    }
+  }
+  return cf;
+}
+
+template <int VEC>
+__device__ __forceinline__ float small_row_grad(const float* src, float* dst, int V, int blank, float4 cf, float sc) {
+  const float c2 = cf.x, pb = cf.y, pl = cf.z;
+  const int lab = __float_as_int(cf.w);
+  float sq = 0.f;
+  for (int i = 0; i < V; i += VEC) {
+    float c[VEC];
+    if constexpr (VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(src + i); c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w; }
+    else if constexpr (VEC == 2) { const float2 q = *reinterpret_cast<const float2*>(src + i); c[0] = q.x; c[1] = q.y; }
+    else { c[0] = src[i]; }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      float gv = fast_exp2(__builtin_fmaf(c[q], kLog2e, c2));
+      gv -= (i + q == blank) ? pb : 0.f;
+      gv -= (i + q == lab) ? pl : 0.f;
+      gv *= sc;
+      sq = __builtin_fmaf(gv, gv, sq);
+      c[q] = gv;
+    }
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + i) = make_float4(c[0], c[1], c[2], c[3]);
+    else if constexpr (VEC == 2) *reinterpret_cast<float2*>(dst + i) = make_float2(c[0], c[1]);
+    else dst[i] = c[0];
+  }
+  return sq;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, float* grad,
+                                                            const int32_t* __restrict__ labels,
+                                                            const int32_t* __restrict__ in_len,
+                                                            const int32_t* __restrict__ lab_len,
+                                                            const float* __restrict__ grad_scale, SmallGeom g, Ws w) {
+  extern __shared__ float4 lds4[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int V = g.V;
+  const int tile_f4 = 16 * V;
+  float4* tile4 = lds4 + wv * tile_f4;
+  float* rowp = reinterpret_cast<float*>(tile4) + lane * V;
+  const int gw = blockIdx.x * kSmallWaves + wv, nw = gridDim.x * kSmallWaves;
+  const f4v* x4 = reinterpret_cast<const f4v*>(x);
+  f4v* g4 = reinterpret_cast<f4v*>(grad);
+  if (blockIdx.x == 0 && threadIdx.x == 0) w.hdr->n_partial = gridDim.x;
+
+  // rows [row_lo(i), row_hi(i)] of a tile overlap its i-th KiB: that load is needed iff one of them is active
+  auto chunk_needed = [&](unsigned long long active, int i) {
+    const int row_bytes = 4 * V;
+    const int lo = (1024 * i) / row_bytes;
+    const int hi = min(63, (1024 * i + 1023) / row_bytes);
+    const unsigned long long m = (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+    return (active & m) != 0ull;
+  };
+
+  int cb = -1, cT = 0, cU = 0;  // lengths cache of small_decode
+  auto raw_of = [&](int n, float& sc) {
+    int t, u;
+    bool in_range;
+    small_decode((long long)n * 64 + lane, g, in_len, lab_len, cb, t, u, cT, cU, in_range);
+    sc = grad_scale ? grad_scale[cb] : 1.f;
+    return cell_load(w, labels, cb, t, u, cT, cU, g.maxT, g.maxU1, V, in_range);
+  };
+
+  f4v st[kSmallNld];
+  auto issue = [&](int n, unsigned long long active) {
+    const f4v* src = x4 + (size_t)n * tile_f4;
+#pragma unroll
+    for (int i = 0; i < kSmallNld; ++i) {
+      const int q = lane + 64 * i;
+      if (chunk_needed(active, i) && q < tile_f4) st[i] = __builtin_nontemporal_load(src + q);
+    }
+  };
+
+  float sqsum = 0.f;
+  // Tiles are taken in the reverse of k_lse_small's order (most recently read rows first).  Three stages are in
+  // flight: the cell state of tile k+2, the logits of tile k+1 (gated by which of its rows are active) and the
+  // arithmetic of tile k.
+  const int last = g.ntiles_full - 1;
+  int k = gw;
+  float4 cf = make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
+  float sc = 1.f, sc_raw = 1.f;
+  unsigned long long active = 0ull;
+  CellRaw raw;
+  raw.flags = 0;
+  if (k < g.ntiles_full) {
+    const CellRaw r0 = raw_of(last - k, sc);
+    cf = cell_coef(r0);
+    active = __ballot(cf.x > -INFINITY);
+    issue(last - k, active);
+    if (k + nw < g.ntiles_full) raw = raw_of(last - (k + nw), sc_raw);
+  }
+  for (; k < g.ntiles_full; k += nw) {
+    const int n = last - k;
+#pragma unroll
+    for (int i = 0; i < kSmallNld; ++i) {
+      const int q = lane + 64 * i;
+      if (chunk_needed(active, i) && q < tile_f4) tile4[q] = make_float4(st[i].x, st[i].y, st[i].z, st[i].w);
+    }
+    const float4 ccf = cf;
+    const float csc = sc;
+    if (k + nw < g.ntiles_full) {
+      cf = cell_coef(raw);  // loaded one iteration ago
+      sc = sc_raw;
+      active = __ballot(cf.x > -INFINITY);
+      issue(last - (k + nw), active);
+      if (k + 2 * nw < g.ntiles_full) raw = raw_of(last - (k + 2 * nw), sc_raw);
+    }
+    if (ccf.x > -INFINITY) {
+      sqsum += small_row_grad<VEC>(rowp, rowp, V, g.blank, ccf, csc);
+    } else {
+      for (int i = 0; i < V; i += VEC) {
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(rowp + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if constexpr (VEC == 2) *reinterpret_cast<float2*>(rowp + i) = make_float2(0.f, 0.f);
+        else rowp[i] = 0.f;
+      }
+    }
+    // the whole tile (gradients and zero rows) leaves as coalesced 1 KiB stores
+    f4v* dst = g4 + (size_t)n * tile_f4;
+#pragma unroll
+    for (int i = 0; i < kSmallNld; ++i) {
+      const int q = lane + 64 * i;
+      if (q < tile_f4) {
+        const float4 o = tile4[q];
+        f4v ov = {o.x, o.y, o.z, o.w};
+        __builtin_nontemporal_store(ov, dst + q);
+      }
+    }
+  }
+  // the last, partial tile: rows handled one per lane straight in global memory
+  if (gw == 0 && (long long)g.ntiles_full * 64 < g.total_rows) {
+    const long long row = (long long)g.ntiles_full * 64 + lane;
+    int b = -1, t, u, T = 0, U = 0;
+    bool in_range;
+    small_decode(row, g, in_len, lab_len, b, t, u, T, U, in_range);
+    if (row < g.total_rows) {
+      const float4 c = cell_coef(cell_load(w, labels, b, t, u, T, U, g.maxT, g.maxU1, V, in_range));
+      float* gp = grad + (size_t)row * V;
+      if (c.x > -INFINITY) {
+        sqsum += small_row_grad<1>(x + (size_t)row * V, gp, V, g.blank, c, grad_scale ? grad_scale[b] : 1.f);
+      } else {
+        for (int i = 0; i < V; ++i) gp[i] = 0.f;
+      }
+    }
+  }
+  __shared__ float red[kSmallWaves];
+  sqsum = group_sum<64>(sqsum);
+  if (lane == 0) red[wv] = sqsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kSmallWaves; ++i) s += red[i];
+    w.partial[blockIdx.x] = s;
+  }
+}
+
+}  // namespace

@@ -1,0 +1,202 @@
+// Part of the single translation unit rnnt_mi355x.hip: k_sweep, the alpha / beta recursions over anti-diagonals.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "workspace.h"
+#include "device_util.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// k_sweep: alpha (even blocks) and beta (odd blocks) anti-diagonal sweeps.
+// One wavefront per (utterance, direction); lane l owns the K lattice columns
+// u = l*K .. l*K+K-1, so one cross-lane shift (DPP, no LDS) per diagonal is the
+// only communication and no barrier sits on the dependent chain.  Cells
+// outside the lattice are handled by masking the log-probs that lead into or
+// out of them to "log 0": their alpha/beta then evaluate to ~-1e30 by
+// themselves.  The log-prob rows of the next P diagonals are kept in flight in
+// a register ring.  A diagonal costs the latency of one dependent chain
+// (add, shift, subtract, exp2, log2, add), not issue slots: splitting the
+// columns of a direction over two wavefronts (one column per lane, boundary
+// value through LDS two diagonals ahead, one s_barrier per diagonal) measured
+// 2.5x slower, 207 us against 83 us at T=400, U=100.  Carrying alpha and beta
+// in the linear domain as (float64 mantissa, int32 exponent) pairs -- multiply,
+// ldexp, add, frexp instead of exp2/log2 on the chain -- gave the same results
+// and was also slower (one column per lane 77 us against 61 us, two columns
+// 135 us against 76 us at T=500): the float64 ldexp/frexp steps cost more than
+// the transcendentals they replace.  Measured per diagonal: 109 ns with one
+// column per lane, 127 ns with two, 230 ns with four, 494 ns with eight.
+// ---------------------------------------------------------------------------
+// lane i receives lane i-1's value; lane 0 receives `fill`
+__device__ __forceinline__ double lane_shift_up(double v, double fill) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// lane i receives lane i+1's value; lane 63 receives `fill`
+__device__ __forceinline__ double lane_shift_down(double v, double fill) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Log-probs {blank, label} of the cells (d-u, u) of diagonal d for this lane's K columns.  Records are in [t][u]
+// order, so the lanes of a diagonal read with a stride of maxU1-1 records; a cache line serves 8 diagonals.
+// Frames are clamped into the guard frames (-1 and maxT), columns beyond maxU1-1 read column maxU1-1 of the
+// guard frame; everything outside the lattice reads "log 0".  rec0 = record of frame -1, column 0.
+template <int K>
+__device__ __forceinline__ void load_lp_diag(const float4* rec0, int d, int maxT, int maxU1, const int (&ucol)[K],
+                                             const int (&uoff)[K], float (&pb)[K], float (&pl)[K]) {
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int t1 = min(max(d - ucol[i], -1), maxT) + 1;                    // frame index incl. guards (v_med3_i32)
+    // 24-bit multiply-add (full rate; t1 <= maxT + 1 < 2^24, maxU1 <= 1024), 32-bit byte offset from a uniform base
+    const unsigned off = __umul24((unsigned)t1, (unsigned)maxU1) + (unsigned)uoff[i];  // uoff = min(u, maxU1-1) or a guard slot
+    const float2 q = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rec0) + (size_t)(off << 4));
+    pb[i] = q.x;
+    pl[i] = q.y;
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void store_row(double* base, int row, unsigned U1s, int u0, const double (&v)[K]) {
+  double* p = base + ((unsigned)row * U1s + (unsigned)u0);
+  if constexpr (K == 1) {
+    p[0] = v[0];
+  } else {
+#pragma unroll
+    for (int i = 0; i < K; i += 2) *reinterpret_cast<double2*>(p + i) = make_double2(v[i], v[i + 1]);
+  }
+}
+
+// log2(2^x + 2^y) with the sum in float64 and the correction term in float32
+__device__ __forceinline__ double log2_add(double x, double y) {
+  const float df = (float)(x - y);
+  return fmax(x, y) + (double)fast_log2(1.0f + fast_exp2(-fabsf(df)));
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, const int32_t* __restrict__ in_len,
+                                              const int32_t* __restrict__ lab_len, int B, int maxT, int maxU1,
+                                              int b0) {
+  constexpr int P = 4;  // diagonals of log-probs kept in flight ahead of the dependent chain
+  const int b = b0 + (blockIdx.x >> 1);
+  const int dir = blockIdx.x & 1;
+  const int lane = threadIdx.x;
+  const int Traw = in_len[b], Uraw = lab_len[b];
+  const bool ok = (Traw >= 1) & (Traw <= maxT) & (Uraw >= 0) & (Uraw <= maxU1 - 1);
+  if (!ok) {
+    if (lane == 0) {
+      atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LENGTH);
+      w.ll[dir * B + b] = 0.0;
+      if (dir == 0) costs[b] = __builtin_nanf("");
+    }
+    return;
+  }
+  const int T = Traw, U = Uraw;
+  const unsigned U1s = (unsigned)w.U1s;
+  const size_t plane = (size_t)b * w.D * U1s;
+  const float4* rec0 = w.rec + (size_t)b * (maxT + 2) * maxU1;  // frame -1 (guard), column 0
+  const int u0 = lane * K;
+  const int dlast = T - 1 + U;
+
+  // columns beyond maxU1-1 have no record: they read the guard frame (frame index forced to -1 by a huge column)
+  int ucol[K], uoff[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int u = u0 + i;
+    const bool has = u < maxU1;
+    ucol[i] = has ? u : (1 << 28);
+    uoff[i] = has ? u : 0;
+  }
+
+  if (dir == 0) {
+    double* alpha = w.alpha + plane;
+    double a[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) a[i] = (u0 + i == 0) ? 0.0 : kNeg;
+    store_row<K>(alpha, 0, U1s, u0, a);
+    // one diagonal: a <- alpha(d) from alpha(d-1) and the log-probs of diagonal d-1
+    auto step = [&](int d, const float (&pb)[K], const float (&pl)[K]) {
+      double el[K];
+#pragma unroll
+      for (int i = 0; i < K; ++i) el[i] = a[i] + (double)pl[i];
+      const double from_left = lane_shift_up(el[K - 1], kNeg);
+#pragma unroll
+      for (int i = 0; i < K; ++i) a[i] = log2_add(a[i] + (double)pb[i], (i == 0) ? from_left : el[i - 1]);
+      store_row<K>(alpha, d, U1s, u0, a);
+    };
+    int d = 1;
+    // remainder first, so that the pipelined loop below runs whole groups of P
+    for (const int rem = dlast % P; d <= rem; ++d) {
+      float pb[K], pl[K];
+      load_lp_diag<K>(rec0, d - 1, maxT, maxU1, ucol, uoff, pb, pl);
+      step(d, pb, pl);
+    }
+    if (d <= dlast) {
+      float pb[P][K], pl[P][K];
+#pragma unroll
+      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec0, d - 1 + p, maxT, maxU1, ucol, uoff, pb[p], pl[p]);
+      for (; d <= dlast; d += P) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          step(d + p, pb[p], pl[p]);
+          load_lp_diag<K>(rec0, d + p - 1 + P, maxT, maxU1, ucol, uoff, pb[p], pl[p]);
+          __builtin_amdgcn_sched_barrier(0);  // keep the refill P diagonals ahead of its use
+        }
+      }
+    }
+    // log2-likelihood = alpha(T-1,U) + log2 P(blank | T-1,U): column U of the last diagonal
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      if (u0 + i == U) {
+        const double ll2 = a[i] + (double)rec0[(size_t)T * maxU1 + U].x;  // frame T-1 is at index T
+        w.ll[b] = ll2;
+        costs[b] = (float)(-ll2 * kLn2);
+      }
+    }
+  } else {
+    double* beta = w.beta + plane;
+    // virtual diagonal dlast+1: beta(T,U) = log 1, everything else log 0
+    double bt[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) bt[i] = (u0 + i == U) ? 0.0 : kNeg;
+    // one diagonal: bt <- beta(d) from beta(d+1) and the log-probs of diagonal d
+    auto step = [&](int d, const float (&pb)[K], const float (&pl)[K]) {
+      const double from_right = lane_shift_down(bt[0], kNeg);
+      double nb[K];
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+        nb[i] = log2_add(bt[i] + (double)pb[i], ((i == K - 1) ? from_right : bt[i + 1]) + (double)pl[i]);
+#pragma unroll
+      for (int i = 0; i < K; ++i) bt[i] = nb[i];
+      store_row<K>(beta, d, U1s, u0, bt);
+    };
+    int d = dlast;
+    for (int rem = (dlast + 1) % P; rem > 0; --rem, --d) {
+      float pb[K], pl[K];
+      load_lp_diag<K>(rec0, d, maxT, maxU1, ucol, uoff, pb, pl);
+      step(d, pb, pl);
+    }
+    if (d >= 0) {
+      float pb[P][K], pl[P][K];
+#pragma unroll
+      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec0, d - p, maxT, maxU1, ucol, uoff, pb[p], pl[p]);
+      for (; d >= 0; d -= P) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          step(d - p, pb[p], pl[p]);
+          load_lp_diag<K>(rec0, d - p - P, maxT, maxU1, ucol, uoff, pb[p], pl[p]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (lane == 0) w.ll[B + b] = bt[0];
+  }
+}
+
+}  // namespace

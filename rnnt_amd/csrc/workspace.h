@@ -1,0 +1,139 @@
+// Part of the single translation unit rnnt_mi355x.hip: constants, the workspace header and layout, launch geometry of the row kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/rnnt_mi355x.h"
+
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr double kLn2 = 0.6931471805599453;
+constexpr float kNegF = -1.0e30f;  // "log 0" that stays finite under addition
+constexpr double kNeg = -1.0e30;
+constexpr int kMaxU1 = 1024;
+constexpr int kRowBlock = 256;  // threads per block of the streaming kernels
+constexpr int kRowWaves = kRowBlock / 64;
+// Lattice cells whose occupancy gamma = exp(alpha+beta-ll) is below 2^kPruneLog2 (~9e-13) get an exactly zero
+// gradient row: every element of that row is bounded by gamma, far below float32 resolution of any sum it
+// could enter.  Their logits are then not read a second time.
+constexpr float kPruneLog2 = -40.f;
+
+// First bytes of the workspace, written on the device.
+struct Header {
+  int32_t flags;          // OR of RNNT_MI355X_FLAG_*
+  int32_t n_partial;      // entries of `partial` the last k_grad wrote
+  uint64_t partial_off;   // byte offset of `partial` from the workspace base
+  int32_t n_fallback;     // fused joint: lattice cells whose linear-domain sum underflowed (handled by the exp path)
+  int32_t pad[59];
+};
+static_assert(sizeof(Header) == 256, "header is one 256-byte block");
+
+struct Ws {
+  Header* hdr;
+  double* ll;      // [2][B]  log2-likelihood from alpha / from beta
+  float* partial;  // [B*maxT] per-block sum of squared gradient elements
+  // [B][maxT+2][maxU1] {log2 P(blank|t,u), log2 P(label u+1|t,u), log2-sum-exp2 of the row, 0}; frame t lives at
+  // index t+1, frames -1 and maxT are guards.  Every entry that is not a lattice cell (guards, t >= T_b,
+  // u > U_b) and the label slot of column U_b hold "log 0", so the sweeps need no masks.
+  float4* rec;
+  double* alpha;   // [B][D][U1s]
+  double* beta;    // [B][D][U1s]
+  // fused additive joint only:
+  float* mf2;      // [B][maxT]  max_v f(b,t,v) * log2(e)
+  float* mg2;      // [B][maxU1] max_v g(b,u,v) * log2(e)
+  float4* coef;    // [B][maxT][maxU1] {c, pb, pl, label code} per cell (c = -inf: no gradient)
+  // Operands of the three contractions, zero-padded, each stored in tiles of 32 rows x 8 columns
+  // ([row tile][column chunk][32][8], see tiled_off) so that every wavefront load is a run of whole cache lines:
+  float* Fp;       // [B] rows t < Tp,  columns v < Vp:  2^(f*log2e - mf2)
+  float* Gp;       // [B] rows u < U1p, columns v < Vp:  2^(g*log2e - mg2)
+  float* Ctu;      // [B] rows t < Tp,  columns u < U1p: C = s_b * gamma / (cell sum); 0 where nothing flows through the products
+  float* Cut;      // [B] rows u < U1p, columns t < Tp:  the same numbers transposed
+  int* head_of;    // [B][Vp]       first position u whose target symbol is v (the blank's is U_b + 1), or -1
+  int* nxt;        // [B][maxU1+2]  next position with the same target as position u, or -1
+  float* rowpart;  // [B][Tp][U1p/32] sums of s*pb(t,u) over runs of 32 positions
+  int Vp, U1p, Tp; // padded extents: maxT and maxU1 rounded up to 32, V to 32 / 64 / a multiple of 128
+  size_t partial_off;
+  int D;    // diagonals = maxT + maxU1 - 1
+  int U1s;  // row stride = 64 * sweep_cols_per_lane(maxU1)
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Lattice columns each lane of a sweep wavefront owns (1, 2, 4, 8 or 16).  The
+// row stride of the per-cell arrays is 64 times this, so that every lane of a
+// sweep can load and store its columns unconditionally.
+inline int sweep_cols_per_lane(int maxU1) {
+  return maxU1 <= 64 ? 1 : maxU1 <= 128 ? 2 : maxU1 <= 256 ? 4 : maxU1 <= 512 ? 8 : 16;
+}
+
+// Lays the workspace out; returns total bytes.  base may be null (size query).
+size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = false, int V = 0) {
+  const int D = maxT + maxU1 - 1;
+  const int U1s = 64 * sweep_cols_per_lane(maxU1);
+  const size_t plane = (size_t)B * D * U1s;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  const size_t o_hdr = take(sizeof(Header));
+  const size_t o_ll = take(sizeof(double) * 2 * B);
+  const size_t o_partial = take(sizeof(float) * (size_t)B * maxT);
+  const size_t o_rec = take(sizeof(float4) * (size_t)B * (maxT + 2) * maxU1);
+  const size_t o_alpha = take(sizeof(double) * plane);
+  const size_t o_beta = take(sizeof(double) * plane);
+  const size_t o_mf2 = joint ? take(sizeof(float) * (size_t)B * maxT) : 0;
+  const size_t o_mg2 = joint ? take(sizeof(float) * (size_t)B * maxU1) : 0;
+  const size_t o_coef = joint ? take(sizeof(float4) * (size_t)B * maxT * maxU1) : 0;
+  const int Vp = V <= 32 ? 32 : V <= 64 ? 64 : (int)align_up((size_t)V, 128);
+  const int U1p = (int)align_up((size_t)maxU1, 32), Tp = (int)align_up((size_t)maxT, 32);
+  const size_t o_Fp = joint ? take(sizeof(float) * (size_t)B * Tp * Vp) : 0;
+  const size_t o_Gp = joint ? take(sizeof(float) * (size_t)B * U1p * Vp) : 0;
+  const size_t o_Ctu = joint ? take(sizeof(float) * (size_t)B * Tp * U1p) : 0;
+  const size_t o_Cut = joint ? take(sizeof(float) * (size_t)B * Tp * U1p) : 0;
+  const size_t o_head = joint ? take(sizeof(int) * (size_t)B * Vp) : 0;
+  const size_t o_nxt = joint ? take(sizeof(int) * (size_t)B * (maxU1 + 2)) : 0;
+  const size_t o_rowpart = joint ? take(sizeof(float) * (size_t)B * Tp * (U1p / 32)) : 0;
+  if (w) {
+    w->hdr = reinterpret_cast<Header*>(p + o_hdr);
+    w->ll = reinterpret_cast<double*>(p + o_ll);
+    w->partial = reinterpret_cast<float*>(p + o_partial);
+    w->rec = reinterpret_cast<float4*>(p + o_rec);
+    w->alpha = reinterpret_cast<double*>(p + o_alpha);
+    w->beta = reinterpret_cast<double*>(p + o_beta);
+    w->mf2 = joint ? reinterpret_cast<float*>(p + o_mf2) : nullptr;
+    w->mg2 = joint ? reinterpret_cast<float*>(p + o_mg2) : nullptr;
+    w->coef = joint ? reinterpret_cast<float4*>(p + o_coef) : nullptr;
+    w->Fp = joint ? reinterpret_cast<float*>(p + o_Fp) : nullptr;
+    w->Gp = joint ? reinterpret_cast<float*>(p + o_Gp) : nullptr;
+    w->Ctu = joint ? reinterpret_cast<float*>(p + o_Ctu) : nullptr;
+    w->Cut = joint ? reinterpret_cast<float*>(p + o_Cut) : nullptr;
+    w->head_of = joint ? reinterpret_cast<int*>(p + o_head) : nullptr;
+    w->nxt = joint ? reinterpret_cast<int*>(p + o_nxt) : nullptr;
+    w->rowpart = joint ? reinterpret_cast<float*>(p + o_rowpart) : nullptr;
+    w->Vp = Vp; w->U1p = U1p; w->Tp = Tp;
+    w->partial_off = o_partial;
+    w->D = D;
+    w->U1s = U1s;
+  }
+  return off;
+}
+
+// Geometry of the streaming kernels: one block per (utterance, TT frames).
+struct RowGeom {
+  int maxT, maxU1, V, blank;
+  int TT;     // frames per block
+  int nTB;    // frame blocks per utterance
+  int npass;  // passes of NC chunks per lane over one row
+  int b0;     // first utterance of this launch
+  size_t xstride;   // elements between consecutive utterances of the logits (>= maxT*maxU1*V)
+  size_t gstride;   // same for the gradient buffer
+  int nblocks;      // blocks of this launch = (utterances of this launch) * nTB
+  int nblocks_all;  // blocks of the whole batch = B * nTB
+};
+
+}  // namespace
