@@ -501,15 +501,15 @@ __device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = min(m0 + mm_row(r, lane), m_real - 1);
-          float corr = 0.f;
+          double corr = 0.0;  // float64: see k_joint_corr_f
           for (int kk = k; kk >= 0; kk = dc.nxt[kk]) {
             if (kk == dc.blank_pos) {
-              for (int q = 0; q < dc.nub; ++q) corr += dc.rowpart[(size_t)m * dc.nub + q];
+              for (int q = 0; q < dc.nub; ++q) corr += (double)dc.rowpart[(size_t)m * dc.nub + q];
             } else {
-              corr += dc.coef[(size_t)m * dc.maxU1 + kk].z;
+              corr += (double)dc.coef[(size_t)m * dc.maxU1 + kk].z;
             }
           }
-          acc[j][r] -= corr;
+          acc[j][r] -= (float)corr;
         }
       }
     }
@@ -639,9 +639,11 @@ __global__ __launch_bounds__(256) void k_joint_corr_f(float* __restrict__ df, co
     const int i = idx / (U + 2), u = idx - i * (U + 2);
     if (!head[u]) continue;
     const float* vr = val + (size_t)i * n;
-    float sacc = 0.f;
-    for (int k = u; k >= 0; k = nxt[k]) sacc += vr[k];
-    df[(size_t)b * jg.dfstride + (size_t)(t0 + i) * jg.V + tgt[u]] -= sacc;
+    // float64: a chain can hold hundreds of nearly equal terms (a symbol repeated along the whole utterance), whose
+    // float32 running sum rounds the same way at every step
+    double sacc = 0.0;
+    for (int k = u; k >= 0; k = nxt[k]) sacc += (double)vr[k];
+    df[(size_t)b * jg.dfstride + (size_t)(t0 + i) * jg.V + tgt[u]] -= (float)sacc;
   }
 }
 
@@ -687,38 +689,38 @@ __global__ __launch_bounds__(256) void k_joint_labelmap(const int32_t* __restric
 __global__ __launch_bounds__(1024) void k_joint_corr_g(float* __restrict__ dg, const int32_t* __restrict__ labels,
                                                        const int32_t* __restrict__ in_len,
                                                        const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
-  __shared__ float red[2][16][64];
+  __shared__ double red[2][16][64];  // float64 sums: see k_joint_corr_f
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ublocks = (jg.maxU1 + 63) / 64;
   const int b = blockIdx.x / ublocks;
   const int u = (blockIdx.x - b * ublocks) * 64 + lane;
   int T, U;
   utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
-  float sb = 0.f, sl = 0.f;
+  double sb = 0.0, sl = 0.0;
   if (u <= U) {
     const float4* cfb = w.coef + (size_t)b * jg.maxT * jg.maxU1 + u;
     for (int t = wv; t < T; t += 16) {
       const float4 cf = cfb[(size_t)t * jg.maxU1];
-      sb += cf.y;
-      sl += cf.z;
+      sb += (double)cf.y;
+      sl += (double)cf.z;
     }
   }
   red[0][wv][lane] = sb;
   red[1][wv][lane] = sl;
   __syncthreads();
   if (wv == 0 && u <= U && T > 0) {
-    sb = 0.f;
-    sl = 0.f;
+    sb = 0.0;
+    sl = 0.0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       sb += red[0][i][lane];
       sl += red[1][i][lane];
     }
     float* out = dg + ((size_t)b * jg.maxU1 + u) * jg.V;
-    out[jg.blank] -= sb;
+    out[jg.blank] -= (float)sb;
     if (u < U) {
       const int l = labels[(size_t)b * (jg.maxU1 - 1) + u];
-      out[(l < 0 || l >= jg.V) ? 0 : l] -= sl;
+      out[(l < 0 || l >= jg.V) ? 0 : l] -= (float)sl;
     }
   }
 }

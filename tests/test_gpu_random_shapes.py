@@ -1,0 +1,128 @@
+"""Seeded random shapes through the three loss surfaces (materialised logits through the C ABI, crop along T inside
+the library, additive joint fused into the loss), each against the float64 oracle.  The parametrised tests elsewhere
+pick one shape per kernel instantiation; these draw extents, lengths, blank position, logit spread and upstream
+scales together, so that combinations nobody listed (odd vocabularies with ragged tiles, a blank in the middle, label
+counts next to a sweep width boundary, ...) are exercised as well.  Same bars: cost 1e-5 relative, gradient 1e-4
+absolute."""
+import numpy as np
+import pytest
+import torch
+
+import rnnt_amd
+from oracle import rnnt_oracle as orc
+from tests.hip_runner import HipRun
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+COST_RTOL = 1e-5
+GRAD_ATOL = 1e-4
+# A one-cell utterance whose only path is near-certain costs ~1e-3 or less.  Its float32 sum of exponentials is
+# 1 + tiny, good to one ulp of 1 (6e-8) whatever the implementation, and the logits of such a row are large, so the
+# cost carries a few 1e-7 absolute: the relative bar needs a floor there.
+COST_ATOL = 1e-6
+
+
+def _draw(seed, max_cells=40_000, max_elems=6_000_000, vmax=1200):
+    """One random problem.  Extents are drawn log-uniformly so that small and large ones are equally likely."""
+    rng = np.random.default_rng(seed)
+
+    def logint(lo, hi):
+        return int(round(np.exp(rng.uniform(np.log(lo), np.log(hi + 0.49)))))
+
+    while True:
+        B = int(rng.integers(1, 6))
+        T = logint(1, 150)
+        U = logint(1, 330) - 1
+        V = logint(2, vmax)
+        if B * T * (U + 1) <= max_cells and B * T * (U + 1) * V <= max_elems:
+            break
+    blank = int(rng.integers(0, V))
+    lab = rng.integers(0, V - 1, (B, U)).astype(np.int32)
+    lab[lab >= blank] += 1
+    if rng.random() < 0.3 and U > 1:  # long runs of one symbol
+        lab[:, : U // 2] = lab[:, :1]
+    il = rng.integers(1, T + 1, B).astype(np.int32)
+    ll = rng.integers(0, U + 1, B).astype(np.int32)
+    k = int(rng.integers(0, B))
+    il[k], ll[k] = T, U
+    scale = float(rng.choice([0.3, 1.0, 3.0, 6.0]))
+    gs = rng.uniform(0.25, 2.0, B).astype(np.float32)
+    return rng, B, T, U, V, blank, lab, il, ll, scale, gs
+
+
+@pytest.mark.parametrize("seed", range(1000, 1060))
+def test_random_logits_through_the_c_abi(seed):
+    rng, B, T, U, V, blank, lab, il, ll, scale, gs = _draw(seed)
+    x = (rng.standard_normal((B, T, U + 1, V)) * scale).astype(np.float32)
+    co, go = orc.rnnt_loss_and_grad(x, lab, il, ll, blank, gs)
+    run = HipRun(x, lab, il, ll, blank, gs)
+    assert run.loss_grad() == 0
+    torch.cuda.synchronize()
+    assert run.flags() == (0, 0)
+    np.testing.assert_allclose(run.costs.cpu().numpy(), co, rtol=COST_RTOL, atol=COST_ATOL, err_msg=str((B, T, U, V, blank)))
+    g = run.x.cpu().numpy()
+    assert np.abs(g - go).max() < GRAD_ATOL, (B, T, U, V, blank)
+    for b in range(B):
+        assert not g[b, il[b]:].any() and not g[b, :, ll[b] + 1:].any()
+
+
+@pytest.mark.parametrize("seed", range(2000, 2040))
+def test_random_crops_along_t(seed):
+    rng, B, T, U, V, blank, lab, il, ll, scale, gs = _draw(seed)
+    off = int(rng.integers(0, 4))  # the reference crops 2 frames (util.py:63,101); other offsets share the code
+    x = (rng.standard_normal((B, T + off, U + 1, V)) * scale).astype(np.float32)
+    co, go = orc.rnnt_loss_and_grad(x[:, off:], lab, il, ll, blank, gs)
+    inplace = bool(seed & 1)
+    base = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    acts = base * 1.0 if inplace else base
+    labels = torch.from_numpy(lab).to(DEV) if U else torch.zeros((B, 0), dtype=torch.int32, device=DEV)
+    costs = rnnt_amd.rnnt_loss(acts, labels, il, ll, blank, t_offset=off, inplace=inplace)
+    (costs * torch.from_numpy(gs).to(DEV)).sum().backward()
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL, atol=COST_ATOL,
+                               err_msg=str((B, T, off, U, V, blank)))
+    g = base.grad.cpu().numpy()
+    assert not g[:, :off].any()
+    assert np.abs(g[:, off:] - go).max() < GRAD_ATOL, (B, T, off, U, V, blank)
+
+
+@pytest.mark.parametrize("seed", range(3000, 3060))
+def test_random_additive_joints(seed):
+    rng, B, T, U, V, blank, lab, il, ll, scale, gs = _draw(seed, vmax=2500)
+    f = (rng.standard_normal((B, T, V)) * scale).astype(np.float32)
+    g = (rng.standard_normal((B, U + 1, V)) * scale).astype(np.float32)
+    co, gj = orc.rnnt_loss_and_grad(f[:, :, None, :] + g[:, None, :, :], lab, il, ll, blank, gs)
+    tf_ = torch.from_numpy(f).to(DEV).requires_grad_(True)
+    tg = torch.from_numpy(g).to(DEV).requires_grad_(True)
+    costs = rnnt_amd.rnnt_joint_loss(tf_, tg, lab, il, ll, blank)
+    (costs * torch.from_numpy(gs).to(DEV)).sum().backward()
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL, atol=COST_ATOL,
+                               err_msg=str((B, T, U, V, blank, scale)))
+    # d f sums the joint gradient over u, d g over t: up to U+1 (T) terms, each within the bar.  With a symbol repeated
+    # a hundred times the sums reach several tens, where float32 itself resolves no better than ~1e-5: hence the
+    # relative term (the same 1e-5 the costs are held to).
+    np.testing.assert_allclose(tf_.grad.cpu().numpy(), gj.sum(2), atol=GRAD_ATOL, rtol=COST_RTOL,
+                               err_msg=str((B, T, U, V, blank, scale)))
+    np.testing.assert_allclose(tg.grad.cpu().numpy(), gj.sum(1), atol=GRAD_ATOL, rtol=COST_RTOL,
+                               err_msg=str((B, T, U, V, blank, scale)))
+
+
+@pytest.mark.parametrize("B,T,U,V", [(2, 1, 225, 2), (2, 300, 0, 2), (2, 300, 1, 3), (1, 40, 200, 2), (2, 2, 240, 300)])
+def test_additive_joint_with_one_symbol_repeated_throughout(B, T, U, V):
+    """Every label the same symbol and (almost) one path through the lattice: the blank / label terms of d f and
+    d g are then hundreds of nearly equal numbers, the case in which a float32 running sum drifts furthest."""
+    rng = np.random.default_rng(B + T + U + V)
+    f = rng.standard_normal((B, T, V)).astype(np.float32)
+    g = rng.standard_normal((B, U + 1, V)).astype(np.float32)
+    lab = np.zeros((B, U), np.int32)
+    il, ll = np.full(B, T, np.int32), np.full(B, U, np.int32)
+    gs = np.array([1.7338928, 1.095334], np.float32)[:B]
+    blank = V - 1
+    co, gj = orc.rnnt_loss_and_grad(f[:, :, None, :] + g[:, None, :, :], lab, il, ll, blank, gs)
+    tf_ = torch.from_numpy(f).to(DEV).requires_grad_(True)
+    tg = torch.from_numpy(g).to(DEV).requires_grad_(True)
+    costs = rnnt_amd.rnnt_joint_loss(tf_, tg, lab, il, ll, blank)
+    (costs * torch.from_numpy(gs).to(DEV)).sum().backward()
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+    np.testing.assert_allclose(tf_.grad.cpu().numpy(), gj.sum(2), atol=GRAD_ATOL, rtol=COST_RTOL)
+    np.testing.assert_allclose(tg.grad.cpu().numpy(), gj.sum(1), atol=GRAD_ATOL, rtol=COST_RTOL)
