@@ -127,10 +127,13 @@ __global__ __launch_bounds__(kRowBlock) void k_lse(const float* __restrict__ x, 
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const float s_all = group_sum<L>(s_run[g]);
-        const float lse2 = m_run[g] * kLog2e + fast_log2(s_all);
+        // log-probabilities as (x*log2e - m2) - log2(s) with the very m2 the sum was built with: their error then
+        // scales with the distance from the row maximum, not with the size of the logits (m2 + log2(s) rounded
+        // first would cost an ulp of the log-sum-exp, 8e-6 at logits near 100)
+        const float m2 = m_run[g] * kLog2e, ls = fast_log2(s_all);
         if (tl.rho[g] >= 0 && j == 0)
-          recs[tl.rho[g]] = make_float4(__builtin_fmaf(exb[g], kLog2e, -lse2),
-                                        tl.haslab[g] ? __builtin_fmaf(exl[g], kLog2e, -lse2) : kNegF, lse2, 0.f);
+          recs[tl.rho[g]] = make_float4(__builtin_fmaf(exb[g], kLog2e, -m2) - ls,
+                                        tl.haslab[g] ? __builtin_fmaf(exl[g], kLog2e, -m2) - ls : kNegF, m2 + ls, 0.f);
       }
     }
   };

@@ -57,8 +57,10 @@ __device__ __forceinline__ void small_decode(long long row, const SmallGeom& g, 
 }
 
 // log-sum-exp2 of one row held in LDS (row-per-lane); VEC = widest aligned access of a row
+// Base-2 maximum m2 and log2 of the sum of 2^(x*log2e - m2) of one row; the log-sum-exp is m2 + ls, and a
+// log-probability is (x*log2e - m2) - ls, whose error scales with the distance from the maximum.
 template <int VEC>
-__device__ __forceinline__ float small_row_lse2(const float* rowp, int V) {
+__device__ __forceinline__ void small_row_lse2(const float* rowp, int V, float& m2, float& ls) {
   float m = -INFINITY;
   for (int i = 0; i < V; i += VEC) {
     float c[VEC];
@@ -68,7 +70,7 @@ __device__ __forceinline__ float small_row_lse2(const float* rowp, int V) {
 #pragma unroll
     for (int q = 0; q < VEC; ++q) m = fmaxf(m, c[q]);
   }
-  const float m2 = m * kLog2e;
+  m2 = m * kLog2e;
   float s = 0.f;
   for (int i = 0; i < V; i += VEC) {
     float c[VEC];
@@ -78,7 +80,7 @@ __device__ __forceinline__ float small_row_lse2(const float* rowp, int V) {
 #pragma unroll
     for (int q = 0; q < VEC; ++q) s += fast_exp2(__builtin_fmaf(c[q], kLog2e, -m2));
   }
-  return m2 + fast_log2(s);
+  ls = fast_log2(s);
 }
 
 // Writes the record of one row (and the guard-frame entries next to frames 0 and maxT-1).
@@ -150,7 +152,8 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
     }
     float4 rc = make_float4(kNegF, kNegF, 0.f, 0.f);
     if (cany && cvalid) {
-      const float lse2 = small_row_lse2<VEC>(rowp, V);
+      float m2, ls;
+      small_row_lse2<VEC>(rowp, V, m2, ls);
       float lpl = kNegF;
       if (cu < cU) {
         int lab = labels[(size_t)cb * (g.maxU1 - 1) + cu];
@@ -158,9 +161,9 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
           atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
           lab = 0;
         }
-        lpl = __builtin_fmaf(rowp[lab], kLog2e, -lse2);
+        lpl = __builtin_fmaf(rowp[lab], kLog2e, -m2) - ls;
       }
-      rc = make_float4(__builtin_fmaf(rowp[g.blank], kLog2e, -lse2), lpl, lse2, 0.f);
+      rc = make_float4(__builtin_fmaf(rowp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, 0.f);
     }
     if (cin) small_write_record(w, g, cb, ct, cu, rc);
   }
@@ -173,7 +176,8 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
       float4 rc = make_float4(kNegF, kNegF, 0.f, 0.f);
       if (t < T && u <= U) {
         const float* rp = x + (size_t)row * V;
-        const float lse2 = small_row_lse2<1>(rp, V);
+        float m2, ls;
+        small_row_lse2<1>(rp, V, m2, ls);
         float lpl = kNegF;
         if (u < U) {
           int lab = labels[(size_t)b * (g.maxU1 - 1) + u];
@@ -181,9 +185,9 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
             atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
             lab = 0;
           }
-          lpl = __builtin_fmaf(rp[lab], kLog2e, -lse2);
+          lpl = __builtin_fmaf(rp[lab], kLog2e, -m2) - ls;
         }
-        rc = make_float4(__builtin_fmaf(rp[g.blank], kLog2e, -lse2), lpl, lse2, 0.f);
+        rc = make_float4(__builtin_fmaf(rp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, 0.f);
       }
       small_write_record(w, g, b, t, u, rc);
     }

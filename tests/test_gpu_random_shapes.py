@@ -21,9 +21,10 @@ GRAD_ATOL = 1e-4
 # 1 + tiny, good to one ulp of 1 (6e-8) whatever the implementation, and the logits of such a row are large, so the
 # cost carries a few 1e-7 absolute: the relative bar needs a floor there.
 COST_ATOL = 1e-6
+SCALES = (0.3, 1.0, 3.0, 6.0)  # standard deviations the logits are drawn with
 
 
-def _draw(seed, max_cells=40_000, max_elems=6_000_000, vmax=1200):
+def _draw(seed, max_cells=40_000, max_elems=6_000_000, vmax=1200, scales=None):
     """One random problem.  Extents are drawn log-uniformly so that small and large ones are equally likely."""
     rng = np.random.default_rng(seed)
 
@@ -46,14 +47,14 @@ def _draw(seed, max_cells=40_000, max_elems=6_000_000, vmax=1200):
     ll = rng.integers(0, U + 1, B).astype(np.int32)
     k = int(rng.integers(0, B))
     il[k], ll[k] = T, U
-    scale = float(rng.choice([0.3, 1.0, 3.0, 6.0]))
+    scale = float(rng.choice(scales or SCALES))
     gs = rng.uniform(0.25, 2.0, B).astype(np.float32)
     return rng, B, T, U, V, blank, lab, il, ll, scale, gs
 
 
 @pytest.mark.parametrize("seed", range(1000, 1060))
-def test_random_logits_through_the_c_abi(seed):
-    rng, B, T, U, V, blank, lab, il, ll, scale, gs = _draw(seed)
+def test_random_logits_through_the_c_abi(seed, scales=None):
+    rng, B, T, U, V, blank, lab, il, ll, scale, gs = _draw(seed, scales=scales)
     x = (rng.standard_normal((B, T, U + 1, V)) * scale).astype(np.float32)
     co, go = orc.rnnt_loss_and_grad(x, lab, il, ll, blank, gs)
     run = HipRun(x, lab, il, ll, blank, gs)
@@ -65,6 +66,15 @@ def test_random_logits_through_the_c_abi(seed):
     assert np.abs(g - go).max() < GRAD_ATOL, (B, T, U, V, blank)
     for b in range(B):
         assert not g[b, il[b]:].any() and not g[b, :, ll[b] + 1:].any()
+
+
+# the first four: draws whose near-zero costs come out 2e-5 .. 4e-3 (relative) off when the log-probabilities are
+# formed as x*log2e - round(log-sum-exp)
+@pytest.mark.parametrize("seed", [50322, 50384, 50575, 50961, *range(4000, 4020)])
+def test_random_logits_with_a_large_spread(seed):
+    """Logits of magnitude 30-150 and near-certain paths (costs down to 1e-5): the per-cell log-probabilities must
+    be accurate relative to the row maximum, not to the size of the logits."""
+    test_random_logits_through_the_c_abi(seed, scales=(10.0, 20.0, 40.0))
 
 
 @pytest.mark.parametrize("seed", range(2000, 2040))

@@ -1,10 +1,15 @@
 import sys, traceback
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tests.test_gpu_random_shapes as t
+# usage: soak_random_shapes.py [cases per surface] [first seed] [logit standard deviations ...]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+if len(sys.argv) > 3:
+    t.SCALES = tuple(float(a) for a in sys.argv[3:])
 bad = 0
-for name, fn, lo in (("abi", t.test_random_logits_through_the_c_abi, 10000), ("crop", t.test_random_crops_along_t, 20000),
-                     ("joint", t.test_random_additive_joints, 30000)):
-    for seed in range(lo, lo + 1500):
+for name, fn, lo in (("abi", t.test_random_logits_through_the_c_abi, first), ("crop", t.test_random_crops_along_t, first + 100000),
+                     ("joint", t.test_random_additive_joints, first + 200000)):
+    for seed in range(lo, lo + n):
         try:
             fn(seed)
         except AssertionError as e:
