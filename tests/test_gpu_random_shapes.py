@@ -136,3 +136,87 @@ def test_additive_joint_with_one_symbol_repeated_throughout(B, T, U, V):
     np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
     np.testing.assert_allclose(tf_.grad.cpu().numpy(), gj.sum(2), atol=GRAD_ATOL, rtol=COST_RTOL)
     np.testing.assert_allclose(tg.grad.cpu().numpy(), gj.sum(1), atol=GRAD_ATOL, rtol=COST_RTOL)
+
+
+def _logint(rng, lo, hi):
+    return int(round(np.exp(rng.uniform(np.log(lo), np.log(hi + 0.49)))))
+
+
+@pytest.mark.parametrize("seed", range(5000, 5030))
+def test_random_dense_layers(seed):
+    """joint_dense (a Dense layer of the reference's get_fc, keras_model.py:83-104) at random widths <= 128."""
+    rng = np.random.default_rng(seed)
+    M, K, N = _logint(rng, 1, 20000), _logint(rng, 1, 128), _logint(rng, 1, 128)
+    act = "tanh" if rng.random() < 0.5 else "linear"
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    k = rng.uniform(-0.3, 0.3, (K, N)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, N).astype(np.float32)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    z = x.astype(np.float64) @ k.astype(np.float64) + b
+    y = np.tanh(z) if act == "tanh" else z
+    g = dy.astype(np.float64) * ((1 - y ** 2) if act == "tanh" else 1.0)
+    tx = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    tk = torch.from_numpy(k).to(DEV).requires_grad_(True)
+    tb = torch.from_numpy(b).to(DEV).requires_grad_(True)
+    out = rnnt_amd.joint_dense(tx, tk, tb, act)
+    out.backward(torch.from_numpy(dy).to(DEV))
+    msg = str((M, K, N, act))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), y, atol=1e-5, err_msg=msg)
+    np.testing.assert_allclose(tx.grad.cpu().numpy(), g @ k.astype(np.float64).T, atol=4e-5 * max(1, N) ** 0.5, err_msg=msg)
+    scale = max(1.0, np.sqrt(M))
+    np.testing.assert_allclose(tk.grad.cpu().numpy(), x.astype(np.float64).T @ g, atol=2e-5 * scale, err_msg=msg)
+    np.testing.assert_allclose(tb.grad.cpu().numpy(), g.sum(0), atol=2e-5 * scale, err_msg=msg)
+
+
+@pytest.mark.parametrize("seed", range(6000, 6024))
+def test_random_fc_joint_heads(seed):
+    """concatenate_lambda + get_fc + rnnt_lambda_func_v2 (util.py:76-90, keras_model.py:83-104, util.py:53-74) with
+    random widths and depths against the oracle, which builds the tiled tensor literally."""
+    rng = np.random.default_rng(seed)
+    B, T0, U = int(rng.integers(1, 4)), _logint(rng, 3, 24), _logint(rng, 1, 14) - 1
+    He, Hd, V = _logint(rng, 1, 200), _logint(rng, 1, 140), _logint(rng, 2, 90)
+    hidden = [_logint(rng, 1, 160) for _ in range(int(rng.integers(0, 4)))]
+    blank = int(rng.integers(0, V))
+    yt = (rng.standard_normal((B, T0, He)) * 0.5).astype(np.float32)
+    yp = (rng.standard_normal((B, U + 1, Hd)) * 0.5).astype(np.float32)
+    dims = [He + Hd] + hidden + [V]
+    ws = [(rng.uniform(-0.5, 0.5, (dims[i], dims[i + 1])).astype(np.float32) / np.sqrt(max(1.0, dims[i] / 16)).astype(np.float32),
+           rng.uniform(-0.1, 0.1, dims[i + 1]).astype(np.float32)) for i in range(len(dims) - 1)]
+    lab = rng.integers(0, V - 1, (B, U)).astype(np.int32)
+    lab[lab >= blank] += 1
+    il = rng.integers(3, T0 + 1, (B, 1)).astype(np.int32)   # lengths before the crop of 2 frames
+    ll = rng.integers(0, U + 1, (B, 1)).astype(np.int32)
+    il[0], ll[0] = T0, U
+    gs = np.full(B, 1.0 / B)
+    co, dt, dp, dws = orc.fc_joint_loss_and_grads(yt, yp, ws, lab, il, ll, blank_label=blank, grad_scale=gs)
+    t_yt = torch.from_numpy(yt).to(DEV).requires_grad_(True)
+    t_yp = torch.from_numpy(yp).to(DEV).requires_grad_(True)
+    t_ws = [(torch.from_numpy(k).to(DEV).requires_grad_(True), torch.from_numpy(b).to(DEV).requires_grad_(True)) for k, b in ws]
+    labels = torch.from_numpy(lab).to(DEV) if U else torch.zeros((B, 0), dtype=torch.int32, device=DEV)
+    costs = rnnt_amd.fc_joint_loss(t_yt, t_yp, t_ws, labels, torch.from_numpy(il).to(DEV), torch.from_numpy(ll).to(DEV),
+                                   blank_label=blank)
+    costs.mean().backward()
+    msg = str((B, T0, U, He, Hd, hidden, V, blank))
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL, atol=COST_ATOL, err_msg=msg)
+    np.testing.assert_allclose(t_yt.grad.cpu().numpy(), dt, atol=GRAD_ATOL, err_msg=msg)
+    np.testing.assert_allclose(t_yp.grad.cpu().numpy(), dp, atol=GRAD_ATOL, err_msg=msg)
+    for (k, b), (dk, db) in zip(t_ws, dws):
+        np.testing.assert_allclose(k.grad.cpu().numpy(), dk, atol=GRAD_ATOL, err_msg=msg)
+        np.testing.assert_allclose(b.grad.cpu().numpy(), db, atol=GRAD_ATOL, err_msg=msg)
+
+
+@pytest.mark.parametrize("seed", range(7000, 7030))
+def test_random_decoder_steps(seed):
+    """Batched joint + Util.softmax(is_log=True) of the decoders (rnnt_decoder.py:156-158,200-202)."""
+    rng = np.random.default_rng(seed)
+    V, nf, ng, n = _logint(rng, 1, 6000), int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.integers(1, 40))
+    scale = float(rng.choice([0.5, 4.0, 20.0]))
+    enc = (rng.standard_normal((nf, V)) * scale).astype(np.float32)
+    pred = (rng.standard_normal((ng, V)) * scale).astype(np.float32)
+    fi, gi = rng.integers(0, nf, n), rng.integers(0, ng, n)
+    out = rnnt_amd.joint_log_softmax(torch.from_numpy(enc).to(DEV), torch.from_numpy(pred).to(DEV),
+                                     torch.from_numpy(fi).to(DEV), torch.from_numpy(gi).to(DEV)).cpu().numpy()
+    for i in range(n):
+        # Util.softmax adds in float32 like the kernel does; its float64 restatement is given the float32 sum
+        want = orc.util_softmax(enc[fi[i]] + pred[gi[i]], is_log=True)
+        np.testing.assert_allclose(out[i], want, atol=1e-5 * max(1.0, scale), err_msg=str((V, nf, ng, n, scale, i)))
