@@ -220,3 +220,42 @@ def test_random_decoder_steps(seed):
         # Util.softmax adds in float32 like the kernel does; its float64 restatement is given the float32 sum
         want = orc.util_softmax(enc[fi[i]] + pred[gi[i]], is_log=True)
         np.testing.assert_allclose(out[i], want, atol=1e-5 * max(1.0, scale), err_msg=str((V, nf, ng, n, scale, i)))
+
+
+@pytest.mark.parametrize("seed", range(8000, 8040))
+def test_random_malformed_lengths_and_labels(seed):
+    """Out-of-range lengths and labels at random places.  The library's contract: the call succeeds, the validation
+    word says what was wrong, an utterance with a bad length gets a NaN cost and a zero gradient, a bad label is
+    computed as label 0, and every other utterance is unaffected."""
+    rng, B, T, U, V, blank, lab, il, ll, scale, gs = _draw(seed, max_cells=8000)
+    x = (rng.standard_normal((B, T, U + 1, V)) * scale).astype(np.float32)
+    il_bad, ll_bad, lab_bad = il.copy(), ll.copy(), lab.copy()
+    bad_len = np.zeros(B, bool)
+    for b in range(B):
+        r = rng.random()
+        if r < 0.25:
+            il_bad[b] = rng.choice([0, -1, T + 1, 2 ** 30, -2 ** 31])
+            bad_len[b] = True
+        elif r < 0.5:
+            ll_bad[b] = rng.choice([-1, U + 1, 2 ** 30, -2 ** 31])
+            bad_len[b] = True
+    want_flags = 1 if bad_len.any() else 0
+    lab_eff = lab.copy()
+    for b in range(B):
+        if U and rng.random() < 0.4:
+            u = int(rng.integers(0, U))
+            lab_bad[b, u] = rng.choice([-1, V, V + 7, 2 ** 31 - 1, -2 ** 31])
+            lab_eff[b, u] = 0
+            if not bad_len[b] and u < ll[b]:   # only labels that are used are looked at
+                want_flags |= 2
+    run = HipRun(x, lab_bad, il_bad, ll_bad, blank, gs)
+    assert run.loss_grad() == 0
+    rc, flags = run.flags()
+    assert flags == want_flags and rc == (4 if want_flags else 0), (flags, want_flags)
+    c, g = run.costs.cpu().numpy(), run.x.cpu().numpy()
+    assert np.isnan(c[bad_len]).all() and not g[bad_len].any()
+    ok = ~bad_len
+    if ok.any():
+        co, go = orc.rnnt_loss_and_grad(x[ok], lab_eff[ok], il[ok], ll[ok], blank, gs[ok])
+        np.testing.assert_allclose(c[ok], co, rtol=COST_RTOL, atol=COST_ATOL)
+        assert np.abs(g[ok] - go).max() < GRAD_ATOL
