@@ -259,3 +259,59 @@ def test_random_malformed_lengths_and_labels(seed):
         co, go = orc.rnnt_loss_and_grad(x[ok], lab_eff[ok], il[ok], ll[ok], blank, gs[ok])
         np.testing.assert_allclose(c[ok], co, rtol=COST_RTOL, atol=COST_ATOL)
         assert np.abs(g[ok] - go).max() < GRAD_ATOL
+
+
+@pytest.mark.parametrize("seed", range(9000, 9030))
+def test_random_malformed_inputs_to_the_fused_joint(seed):
+    """The same contract for the fused joint, through the C ABI (the Python layer would reject these on the host)."""
+    import ctypes
+
+    from rnnt_amd import _lib
+
+    def p(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    rng, B, T, U, V, blank, lab, il, ll, scale, gs = _draw(seed, max_cells=8000, vmax=700)
+    f = (rng.standard_normal((B, T, V)) * scale).astype(np.float32)
+    g = (rng.standard_normal((B, U + 1, V)) * scale).astype(np.float32)
+    il_bad, ll_bad, lab_bad, lab_eff = il.copy(), ll.copy(), lab.copy(), lab.copy()
+    bad_len = np.zeros(B, bool)
+    want_flags = 0
+    for b in range(B):
+        r = rng.random()
+        if r < 0.25:
+            il_bad[b] = rng.choice([0, -1, T + 1, 2 ** 30, -2 ** 31])
+            bad_len[b] = True
+        elif r < 0.5:
+            ll_bad[b] = rng.choice([-1, U + 1, 2 ** 30, -2 ** 31])
+            bad_len[b] = True
+        if U and rng.random() < 0.4:
+            u = int(rng.integers(0, U))
+            lab_bad[b, u] = rng.choice([-1, V, V + 7, 2 ** 31 - 1, -2 ** 31])
+            lab_eff[b, u] = 0
+            if not bad_len[b] and u < ll[b]:
+                want_flags |= 2
+    if bad_len.any():
+        want_flags |= 1
+    L = _lib.lib()
+    tf_, tg = torch.from_numpy(f).to(DEV), torch.from_numpy(g).to(DEV)
+    tl = torch.from_numpy(lab_bad).to(DEV) if U else torch.zeros(1, dtype=torch.int32, device=DEV)
+    til, tll, tgs = (torch.from_numpy(a).to(DEV) for a in (il_bad, ll_bad, gs))
+    ws = torch.empty(_lib.joint_workspace_bytes(B, T, U + 1, V), dtype=torch.uint8, device=DEV)
+    ws.fill_(0xFF)
+    costs = torch.full((B,), 7.0, device=DEV)
+    df, dg = torch.full_like(tf_, 7.0), torch.full_like(tg, 7.0)
+    assert L.rnnt_mi355x_joint_forward(p(tf_), 0, p(tg), p(tl), p(til), p(tll), B, T, U + 1, V, blank, p(costs), p(ws), None) == 0
+    assert L.rnnt_mi355x_joint_backward(p(tf_), 0, p(tg), p(tl), p(til), p(tll), B, T, U + 1, V, blank, p(tgs), p(df), 0,
+                                        p(dg), p(ws), None) == 0
+    flags = ctypes.c_int32(0)
+    rc = L.rnnt_mi355x_read_status(p(ws), ctypes.byref(flags), None)
+    assert flags.value == want_flags and rc == (4 if want_flags else 0), (flags.value, want_flags)
+    c, dfn, dgn = costs.cpu().numpy(), df.cpu().numpy(), dg.cpu().numpy()
+    assert np.isnan(c[bad_len]).all() and not dfn[bad_len].any() and not dgn[bad_len].any()
+    ok = ~bad_len
+    if ok.any():
+        co, gj = orc.rnnt_loss_and_grad((f[:, :, None, :] + g[:, None, :, :])[ok], lab_eff[ok], il[ok], ll[ok], blank, gs[ok])
+        np.testing.assert_allclose(c[ok], co, rtol=COST_RTOL, atol=COST_ATOL)
+        np.testing.assert_allclose(dfn[ok], gj.sum(2), atol=GRAD_ATOL, rtol=COST_RTOL)
+        np.testing.assert_allclose(dgn[ok], gj.sum(1), atol=GRAD_ATOL, rtol=COST_RTOL)

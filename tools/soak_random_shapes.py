@@ -11,7 +11,8 @@ bad = 0
 for name, fn, lo in (("abi", t.test_random_logits_through_the_c_abi, first), ("crop", t.test_random_crops_along_t, first + 100000),
                      ("joint", t.test_random_additive_joints, first + 200000), ("dense", t.test_random_dense_layers, first + 300000),
                      ("fc_joint", t.test_random_fc_joint_heads, first + 400000), ("decode", t.test_random_decoder_steps, first + 500000),
-                     ("malformed", t.test_random_malformed_lengths_and_labels, first + 600000)):
+                     ("malformed", t.test_random_malformed_lengths_and_labels, first + 600000),
+                     ("malformed_joint", t.test_random_malformed_inputs_to_the_fused_joint, first + 700000)):
     if only and name not in only:
         continue
     for seed in range(lo, lo + n):
