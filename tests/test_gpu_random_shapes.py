@@ -22,6 +22,7 @@ GRAD_ATOL = 1e-4
 # cost carries a few 1e-7 absolute: the relative bar needs a floor there.
 COST_ATOL = 1e-6
 SCALES = (0.3, 1.0, 3.0, 6.0)  # standard deviations the logits are drawn with
+MAX_T, MAX_U1, SIZE_FACTOR = 150, 330, 1  # the soak script raises these
 
 
 def _draw(seed, max_cells=40_000, max_elems=6_000_000, vmax=1200, scales=None):
@@ -33,10 +34,10 @@ def _draw(seed, max_cells=40_000, max_elems=6_000_000, vmax=1200, scales=None):
 
     while True:
         B = int(rng.integers(1, 6))
-        T = logint(1, 150)
-        U = logint(1, 330) - 1
+        T = logint(1, MAX_T)
+        U = logint(1, MAX_U1) - 1
         V = logint(2, vmax)
-        if B * T * (U + 1) <= max_cells and B * T * (U + 1) * V <= max_elems:
+        if B * T * (U + 1) <= max_cells * SIZE_FACTOR and B * T * (U + 1) * V <= max_elems * SIZE_FACTOR:
             break
     blank = int(rng.integers(0, V))
     lab = rng.integers(0, V - 1, (B, U)).astype(np.int32)
