@@ -37,11 +37,24 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-o", LIB, *SOURCES]
+    hipcc = hipcc_path()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"]
+    # one object per source, compiled side by side (objects live next to the library, git-ignored), then one link
+    objs = [os.path.splitext(src)[0] + ".o" for src in SOURCES]
+    cmds = [[hipcc, *flags, "-c", src, "-o", obj] for src, obj in zip(SOURCES, objs)]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        for cmd in cmds:
+            print(" ".join(cmd))
+    procs = [subprocess.Popen(cmd) for cmd in cmds]
+    failed = [cmd for cmd, pr in zip(cmds, procs) if pr.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link)
+    for obj in objs:
+        os.remove(obj)
     return LIB
 
 
