@@ -415,3 +415,28 @@ def test_fused_joint_with_masked_vocabulary_entries():
     df, dg = tf_.grad.cpu().numpy(), tg.grad.cpu().numpy()
     assert np.isfinite(df).all() and np.isfinite(dg).all()
     assert np.abs(df - gj.sum(2)).max() < GRAD_ATOL and np.abs(dg - gj.sum(1)).max() < GRAD_ATOL
+
+
+def test_batch_producer_arrays_feed_the_lambda():
+    """pad_batch's arrays (float64 lengths of shape [B], float labels padded with 0: data_generator.py:391-426) go
+    through rnnt_lambda_func as they are -- the casts the Keras Inputs do (keras_model.py:125-127) happen inside."""
+    rng = np.random.default_rng(12)
+    V, F = 41, 6
+    feats = [rng.standard_normal((t, F)) for t in (13, 9, 11)]
+    seqs = [[3, 7, 7, 1], [5], [2, 0, 9]]
+    inputs, _ = rnnt_amd.pad_batch(feats, seqs, vocab_size=V - 1)
+    We, Wd = rng.standard_normal((F, V)) * 0.3, rng.standard_normal((V - 1, V)) * 0.3
+    yt = (inputs["INPUT_TRANS"] @ We).astype(np.float32)          # stand-ins for the two networks
+    yp = (inputs["INPUT_PREDS"] @ Wd).astype(np.float32)
+    t_yt = torch.from_numpy(yt).to(DEV).requires_grad_(True)
+    t_yp = torch.from_numpy(yp).to(DEV).requires_grad_(True)
+    costs = rnnt_amd.rnnt_lambda_func([t_yt, t_yp, inputs["INPUT_LABEL"], inputs["INPUT_INLEN"], inputs["INPUT_LBLEN"]],
+                                      blank_label=V - 1)
+    costs.mean().backward()
+    il = inputs["INPUT_INLEN"].astype(np.int32).reshape(-1, 1)
+    ll = inputs["INPUT_LBLEN"].astype(np.int32).reshape(-1, 1)
+    co, dt, dp = orc.rnnt_lambda_func(yt, yp, inputs["INPUT_LABEL"].astype(np.int32), il, ll, blank_label=V - 1,
+                                      grad_scale=np.full(3, 1 / 3))
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
+    assert np.abs(t_yt.grad.cpu().numpy() - dt).max() < GRAD_ATOL
+    assert np.abs(t_yp.grad.cpu().numpy() - dp).max() < GRAD_ATOL
