@@ -405,7 +405,7 @@ struct DfCorr {
 };
 
 template <int NT, bool CORR>
-__device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, int a_chunks, int kmax,
+__device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, int a_chunks, int kbeg, int kmax,
                                               const float* __restrict__ b_base, const float* __restrict__ e_base,
                                               int Vp, int m0, int n0, int m_real, int V, float* __restrict__ out,
                                               bool vec_ok, int lane, const DfCorr& dc) {
@@ -438,9 +438,9 @@ __device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, 
       for (int j = 0; j < NT; ++j)
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], fvec_get<NT>(bv[i], j), acc[j], 0, 0, 0);
   };
-  if (kmax > 0) {
-    load_set(0, a0, bv0);
-    for (int k0 = 0; k0 < kmax; k0 += 16) {
+  if (kmax > kbeg) {  // K range [kbeg, kmax), both multiples of 8
+    load_set(kbeg, a0, bv0);
+    for (int k0 = kbeg; k0 < kmax; k0 += 16) {
       const bool second = k0 + 8 < kmax;  // uniform
       load_set(second ? k0 + 8 : k0, a1, bv1);
       __builtin_amdgcn_sched_barrier(0);
@@ -555,25 +555,32 @@ __global__ __launch_bounds__(256) void k_joint_df_mm(float* __restrict__ df, con
   dc.coef = w.coef + (size_t)mt.b * jg.maxT * jg.maxU1;
   dc.rowpart = w.rowpart + (size_t)mt.b * w.Tp * (w.U1p >> 5);
   dc.maxU1 = jg.maxU1; dc.nub = w.U1p >> 5; dc.blank_pos = U + 1;
-  joint_grad_mm<NT, CORR>(w.Ctu + cb, w.U1p >> 3, kmax, w.Gp + (size_t)mt.b * w.U1p * w.Vp,
+  joint_grad_mm<NT, CORR>(w.Ctu + cb, w.U1p >> 3, 0, kmax, w.Gp + (size_t)mt.b * w.U1p * w.Vp,
                           w.Fp + (size_t)mt.b * w.Tp * w.Vp, w.Vp, mt.m0, mt.n0, jg.maxT, jg.V,
                           df + (size_t)mt.b * jg.dfstride, vec_ok, threadIdx.x & 63, dc);
 }
 
-// d g(u,v) = G(u,v) * sum_t C(t,u) F(t,v): M = label positions, N = vocabulary, K = frames.
+// d g(u,v) = G(u,v) * sum_t C(t,u) F(t,v): M = label positions, N = vocabulary, K = frames.  With w.dg_split > 1
+// the frames are cut into that many slices, each wavefront tile takes one slice and writes its partial result to
+// w.dgpart; k_joint_corr_g adds the slices up.
 template <int NT>
 __global__ __launch_bounds__(256) void k_joint_dg_mm(float* __restrict__ dg, const int32_t* __restrict__ in_len,
                                                      const int32_t* __restrict__ lab_len, JointGeom jg, Ws w,
                                                      bool vec_ok) {
-  const MmTile mt = mm_tile(jg.B, w.U1p / 32, w.Vp / (32 * NT), 32 * NT);
+  const int ks = w.dg_split;
+  const MmTile mt = mm_tile(jg.B * ks, w.U1p / 32, w.Vp / (32 * NT), 32 * NT);
   if (!mt.ok) return;
+  const int slice_i = mt.b / jg.B, b = mt.b - slice_i * jg.B;  // slices vary slowest
   int T, U;
-  utt_dims(in_len, lab_len, mt.b, jg.maxT, jg.maxU1, T, U);
+  utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
   const int kmax = (mt.m0 <= U) ? (T + 7) & ~7 : 0;  // C is zero in frames >= T_b and columns > U_b
-  const size_t cb = (size_t)mt.b * w.Tp * w.U1p;
-  joint_grad_mm<NT, false>(w.Cut + cb, w.Tp >> 3, kmax, w.Fp + (size_t)mt.b * w.Tp * w.Vp,
-                           w.Gp + (size_t)mt.b * w.U1p * w.Vp, w.Vp, mt.m0, mt.n0, jg.maxU1, jg.V,
-                           dg + (size_t)mt.b * jg.maxU1 * jg.V, vec_ok, threadIdx.x & 63, DfCorr{});
+  const int slice = (kmax + 16 * ks - 1) / (16 * ks) * 16;
+  const int kbeg = min(kmax, slice_i * slice), kend = min(kmax, kbeg + slice);
+  const size_t cb = (size_t)b * w.Tp * w.U1p;
+  float* out = ks > 1 ? w.dgpart + ((size_t)slice_i * jg.B + b) * jg.maxU1 * jg.V : dg + (size_t)b * jg.maxU1 * jg.V;
+  joint_grad_mm<NT, false>(w.Cut + cb, w.Tp >> 3, kbeg, kend, w.Fp + (size_t)b * w.Tp * w.Vp,
+                           w.Gp + (size_t)b * w.U1p * w.Vp, w.Vp, mt.m0, mt.n0, jg.maxU1, jg.V, out, vec_ok,
+                           threadIdx.x & 63, DfCorr{});
 }
 
 // Blank and label terms of d f as a pass of their own (small vocabularies, where labels repeat so often that the
@@ -685,7 +692,8 @@ __global__ __launch_bounds__(256) void k_joint_labelmap(const int32_t* __restric
   }
 }
 
-// Blank and label terms of d g: 64 label positions per block, the frames split over the block's 16 waves.
+// Blank and label terms of d g: 64 label positions per block, the frames split over the block's 16 waves.  When
+// the contraction was cut into slices (w.dg_split > 1) the block first adds the slices of its 64 rows up, in order.
 __global__ __launch_bounds__(1024) void k_joint_corr_g(float* __restrict__ dg, const int32_t* __restrict__ labels,
                                                        const int32_t* __restrict__ in_len,
                                                        const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
@@ -693,7 +701,23 @@ __global__ __launch_bounds__(1024) void k_joint_corr_g(float* __restrict__ dg, c
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ublocks = (jg.maxU1 + 63) / 64;
   const int b = blockIdx.x / ublocks;
-  const int u = (blockIdx.x - b * ublocks) * 64 + lane;
+  const int ub0 = (blockIdx.x - b * ublocks) * 64;
+  const int u = ub0 + lane;
+  if (w.dg_split > 1) {
+    const int rows = min(64, jg.maxU1 - ub0);
+    const size_t base = ((size_t)b * jg.maxU1 + ub0) * jg.V, per_slice = (size_t)jg.B * jg.maxU1 * jg.V;
+    const int ks = w.dg_split;  // 2, 4 or 8
+#pragma unroll 2
+    for (int i = threadIdx.x; i < rows * jg.V; i += 1024) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = k < ks ? w.dgpart[(size_t)k * per_slice + base + i] : 0.f;  // all in flight
+      float acc = v[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) acc += v[k];
+      dg[base + i] = acc;
+    }
+  }
   int T, U;
   utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
   double sb = 0.0, sl = 0.0;
@@ -707,7 +731,7 @@ __global__ __launch_bounds__(1024) void k_joint_corr_g(float* __restrict__ dg, c
   }
   red[0][wv][lane] = sb;
   red[1][wv][lane] = sl;
-  __syncthreads();
+  __syncthreads();  // also orders the sums of slices above before the read-modify-writes below
   if (wv == 0 && u <= U && T > 0) {
     sb = 0.0;
     sl = 0.0;

@@ -378,14 +378,14 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
   const int ns = w.Vp / (32 * nt);
   if (nt == 1) {
     k_joint_df_mm<1, false><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
-    k_joint_dg_mm<1><<<mm_blocks(jg.B, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
+    k_joint_dg_mm<1><<<mm_blocks(jg.B * w.dg_split, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
   } else if (nt == 2) {
     k_joint_df_mm<2, false><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
-    k_joint_dg_mm<2><<<mm_blocks(jg.B, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
+    k_joint_dg_mm<2><<<mm_blocks(jg.B * w.dg_split, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
   } else {
     if (fold) k_joint_df_mm<4, true><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
     else k_joint_df_mm<4, false><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
-    k_joint_dg_mm<4><<<mm_blocks(jg.B, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
+    k_joint_dg_mm<4><<<mm_blocks(jg.B * w.dg_split, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
   }
   if (!fold) {
     const int fb = jg.maxU1 <= 128 ? 32 : jg.maxU1 <= 256 ? 16 : 8;  // frames per block: (3 + fb) * (maxU1 + 1) words of LDS

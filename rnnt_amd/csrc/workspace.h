@@ -53,6 +53,8 @@ struct Ws {
   int* head_of;    // [B][Vp]       first position u whose target symbol is v (the blank's is U_b + 1), or -1
   int* nxt;        // [B][maxU1+2]  next position with the same target as position u, or -1
   float* rowpart;  // [B][Tp][U1p/32] sums of s*pb(t,u) over runs of 32 positions
+  float* dgpart;   // [dg_split][B][maxU1][V] partial d g of each slice of the frames (only when dg_split > 1)
+  int dg_split;    // slices the sum over frames of the d g contraction is cut into (1 = written straight to d g)
   int Vp, U1p, Tp; // padded extents: maxT and maxU1 rounded up to 32, V to 32 / 64 / a multiple of 128
   size_t partial_off;
   int D;    // diagonals = maxT + maxU1 - 1
@@ -66,6 +68,17 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // sweep can load and store its columns unconditionally.
 inline int sweep_cols_per_lane(int maxU1) {
   return maxU1 <= 64 ? 1 : maxU1 <= 128 ? 2 : maxU1 <= 256 ? 4 : maxU1 <= 512 ? 8 : 16;
+}
+
+// The d g contraction has only B * (U1p/32) * (column strips) wavefront tiles, each summing over all frames: for a
+// small vocabulary and few utterances that is a fraction of the 1024 SIMDs with a long serial loop.  The sum over
+// frames is then cut into 2, 4 or 8 slices whose partial results k_joint_corr_g adds up in a fixed order.
+inline int joint_dg_split(int B, int Tp, int U1p, int Vp) {
+  const int nt = Vp <= 32 ? 1 : Vp <= 64 ? 2 : 4;
+  const long long waves = (long long)B * (U1p / 32) * (Vp / (32 * nt));
+  int ks = 1;
+  while (waves * ks < 768 && ks < 8 && Tp / (ks * 2) >= 64) ks *= 2;
+  return ks;
 }
 
 // Lays the workspace out; returns total bytes.  base may be null (size query).
@@ -98,6 +111,8 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
   const size_t o_head = joint ? take(sizeof(int) * (size_t)B * Vp) : 0;
   const size_t o_nxt = joint ? take(sizeof(int) * (size_t)B * (maxU1 + 2)) : 0;
   const size_t o_rowpart = joint ? take(sizeof(float) * (size_t)B * Tp * (U1p / 32)) : 0;
+  const int dg_split = joint ? joint_dg_split(B, Tp, U1p, Vp) : 1;
+  const size_t o_dgpart = dg_split > 1 ? take(sizeof(float) * (size_t)dg_split * B * maxU1 * V) : 0;
   if (w) {
     w->hdr = reinterpret_cast<Header*>(p + o_hdr);
     w->ll = reinterpret_cast<double*>(p + o_ll);
@@ -115,6 +130,8 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
     w->head_of = joint ? reinterpret_cast<int*>(p + o_head) : nullptr;
     w->nxt = joint ? reinterpret_cast<int*>(p + o_nxt) : nullptr;
     w->rowpart = joint ? reinterpret_cast<float*>(p + o_rowpart) : nullptr;
+    w->dgpart = dg_split > 1 ? reinterpret_cast<float*>(p + o_dgpart) : nullptr;
+    w->dg_split = dg_split;
     w->Vp = Vp; w->U1p = U1p; w->Tp = Tp;
     w->partial_off = o_partial;
     w->D = D;

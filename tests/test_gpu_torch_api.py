@@ -188,6 +188,8 @@ JOINT_SHAPES = [  # B, T, U, V, blank -> every elements-per-lane variant of the 
     # several 32-row tiles / column strips of the contractions, ragged edges in every dimension
     (2, 70, 40, 150, 149), (1, 45, 70, 33, 0), (2, 33, 64, 129, 64), (1, 100, 12, 300, 17),
     (1, 6, 600, 9, 8),   # more than 512 label positions
+    # few wavefront tiles in the d g contraction: its sum over frames is cut into 4 / 8 slices
+    (1, 300, 20, 62, 39), (2, 520, 5, 300, 7), (3, 130, 33, 40, 0),
 ]
 
 
@@ -209,9 +211,10 @@ def test_fused_joint_matches_oracle(B, T, U, V, blank):
     costs = rnnt_amd.rnnt_joint_loss(tf_, tg, lab, il, ll, blank)
     (costs * torch.from_numpy(w).to(DEV)).sum().backward()
     np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
-    # d f = sum over u, d g = sum over t of the joint gradient: up to U+1 (T) terms, each within the 1e-4 bar
-    assert np.abs(tf_.grad.cpu().numpy() - gj.sum(2)).max() < GRAD_ATOL
-    assert np.abs(tg.grad.cpu().numpy() - gj.sum(1)).max() < GRAD_ATOL
+    # d f = sum over u, d g = sum over t of the joint gradient: up to U+1 (T) terms, each within the 1e-4 bar; sums
+    # of hundreds of terms reach tens to hundreds, where float32 resolves ~1e-5 of the value: hence the relative term
+    np.testing.assert_allclose(tf_.grad.cpu().numpy(), gj.sum(2), atol=GRAD_ATOL, rtol=COST_RTOL)
+    np.testing.assert_allclose(tg.grad.cpu().numpy(), gj.sum(1), atol=GRAD_ATOL, rtol=COST_RTOL)
 
 
 def test_fused_joint_equals_materialised_path_and_handles_separated_maxima():
