@@ -388,7 +388,9 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
     k_joint_dg_mm<4><<<mm_blocks(jg.B * w.dg_split, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
   }
   if (!fold) {
-    const int fb = jg.maxU1 <= 128 ? 32 : jg.maxU1 <= 256 ? 16 : 8;  // frames per block: (3 + fb) * (maxU1 + 1) words of LDS
+    // frames per block: (3 + fb) * (maxU1 + 1) words of LDS.  8 measured best at T=500, U=100, V=62 (18 us; 16: 20 us,
+    // 32: 26 us): more blocks outweigh building the chains more often.
+    const int fb = 8;
     const size_t corr_lds = sizeof(int) * (3 + fb) * (size_t)(jg.maxU1 + 1);
     k_joint_corr_f<<<jg.B * ((jg.maxT + fb - 1) / fb), 256, corr_lds, st>>>(df, c.labels, c.in_len, c.lab_len, jg, w, fb);
   }
