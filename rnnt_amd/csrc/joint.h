@@ -33,7 +33,8 @@ namespace {
 //   k_joint_labelmap               chains of label positions per symbol: the blank / label terms of d f are
 //                                  subtracted in the epilogue of its contraction
 //   k_joint_corr_g                 the blank / label terms of d g
-//   k_joint_fix_f, k_joint_fix_g   exponent-domain contributions of flagged cells (exit at once when there are none)
+//   k_joint_fix                    exponent-domain contributions of flagged cells to d f and d g (exits at once
+//                                  when there are none)
 // ---------------------------------------------------------------------------
 struct JointGeom {
   int B, maxT, maxU1, V, blank;
@@ -74,6 +75,12 @@ __device__ __forceinline__ void jrow_load(const float* row, int V, int lane, flo
 template <bool VEC4, int NIT>
 __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f, const float* __restrict__ g,
                                                     JointGeom jg, Ws w) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // first kernel of a forward: start the validation word and counters
+    w.hdr->flags = 0;
+    w.hdr->n_fallback = 0;
+    w.hdr->n_partial = 0;
+    w.hdr->partial_off = w.partial_off;
+  }
   const int lane = threadIdx.x & 63;
   const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int ngf = jg.B * (w.Tp / 4), ngg = jg.B * (w.U1p / 4);
@@ -751,16 +758,15 @@ __global__ __launch_bounds__(1024) void k_joint_corr_g(float* __restrict__ dg, c
 
 // Exponent-domain contribution of the flagged cells to d f: a wave owns TT frames and loops over u.
 template <int KE, int TT>
-__global__ __launch_bounds__(256) void k_joint_fix_f(const float* __restrict__ f, const float* __restrict__ g,
-                                                     float* __restrict__ df, const int32_t* __restrict__ in_len,
-                                                     const int32_t* __restrict__ lab_len,
-                                                     const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
-  if (w.hdr->n_fallback == 0) return;
+__device__ __forceinline__ void joint_fix_f(int block, const float* __restrict__ f, const float* __restrict__ g,
+                                            float* __restrict__ df, const int32_t* __restrict__ in_len,
+                                            const int32_t* __restrict__ lab_len,
+                                            const float* __restrict__ grad_scale, const JointGeom& jg, const Ws& w) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ntile = (jg.maxT + TT - 1) / TT;
   const int blocks_per_b = (ntile + 3) / 4;
-  const int b = blockIdx.x / blocks_per_b;
-  const int tile = (blockIdx.x - b * blocks_per_b) * 4 + wv;
+  const int b = block / blocks_per_b;
+  const int tile = (block - b * blocks_per_b) * 4 + wv;
   if (tile >= ntile) return;
   const int t0 = tile * TT;
   const int V = jg.V, maxU1 = jg.maxU1;
@@ -811,16 +817,15 @@ __global__ __launch_bounds__(256) void k_joint_fix_f(const float* __restrict__ f
 
 // Same for d g: a wave owns UU label positions and loops over t.
 template <int KE, int UU>
-__global__ __launch_bounds__(256) void k_joint_fix_g(const float* __restrict__ f, const float* __restrict__ g,
-                                                     float* __restrict__ dg, const int32_t* __restrict__ in_len,
-                                                     const int32_t* __restrict__ lab_len,
-                                                     const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
-  if (w.hdr->n_fallback == 0) return;
+__device__ __forceinline__ void joint_fix_g(int block, const float* __restrict__ f, const float* __restrict__ g,
+                                            float* __restrict__ dg, const int32_t* __restrict__ in_len,
+                                            const int32_t* __restrict__ lab_len,
+                                            const float* __restrict__ grad_scale, const JointGeom& jg, const Ws& w) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ntile = (jg.maxU1 + UU - 1) / UU;
   const int blocks_per_b = (ntile + 3) / 4;
-  const int b = blockIdx.x / blocks_per_b;
-  const int tile = (blockIdx.x - b * blocks_per_b) * 4 + wv;
+  const int b = block / blocks_per_b;
+  const int tile = (block - b * blocks_per_b) * 4 + wv;
   if (tile >= ntile) return;
   const int u0 = tile * UU;
   const int V = jg.V, maxU1 = jg.maxU1;
@@ -867,6 +872,20 @@ __global__ __launch_bounds__(256) void k_joint_fix_g(const float* __restrict__ f
       if (v < V) out[v] += acc[uu][k];
     }
   }
+}
+
+// Both exponent-domain passes in one launch (they touch different outputs): the first f_blocks blocks take d f,
+// the rest d g.  With no flagged cell -- the usual case -- every block returns at once.
+template <int KE, int TT>
+__global__ __launch_bounds__(256) void k_joint_fix(const float* __restrict__ f, const float* __restrict__ g,
+                                                   float* __restrict__ df, float* __restrict__ dg,
+                                                   const int32_t* __restrict__ in_len,
+                                                   const int32_t* __restrict__ lab_len,
+                                                   const float* __restrict__ grad_scale, JointGeom jg, Ws w,
+                                                   int f_blocks) {
+  if (w.hdr->n_fallback == 0) return;
+  if ((int)blockIdx.x < f_blocks) joint_fix_f<KE, TT>(blockIdx.x, f, g, df, in_len, lab_len, grad_scale, jg, w);
+  else joint_fix_g<KE, TT>(blockIdx.x - f_blocks, f, g, dg, in_len, lab_len, grad_scale, jg, w);
 }
 
 }  // namespace

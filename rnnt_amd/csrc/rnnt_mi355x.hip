@@ -328,8 +328,7 @@ inline unsigned mm_blocks(int B, int m_tiles, int n_strips) {
 int launch_joint_forward(const JointCall& c, float* costs, hipStream_t st) {
   const JointGeom& jg = c.jg;
   const Ws& w = c.w;
-  k_init<<<1, 64, 0, st>>>(w, 0);
-  const int groups = jg.B * ((w.Tp + w.U1p) / 4);
+  const int groups = jg.B * ((w.Tp + w.U1p) / 4);  // k_joint_prep also starts the workspace header
   const bool rows16 = jg.V % 4 == 0 && jg.fstride % 4 == 0 && reinterpret_cast<uintptr_t>(c.f) % 16 == 0 &&
                       reinterpret_cast<uintptr_t>(c.g) % 16 == 0;
   const unsigned pgrid = (unsigned)((groups + 3) / 4);
@@ -395,10 +394,13 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
     k_joint_corr_f<<<jg.B * ((jg.maxT + fb - 1) / fb), 256, corr_lds, st>>>(df, c.labels, c.in_len, c.lab_len, jg, w, fb);
   }
   k_joint_corr_g<<<jg.B * ((jg.maxU1 + 63) / 64), 1024, 0, st>>>(dg, c.labels, c.in_len, c.lab_len, jg, w);
-#define JGRID_T(TT) dim3((unsigned)(jg.B * ((((jg.maxT + (TT)-1) / (TT)) + 3) / 4)))
-#define JGRID_U(UU) dim3((unsigned)(jg.B * ((((jg.maxU1 + (UU)-1) / (UU)) + 3) / 4)))
-  RNNT_JOINT_DISPATCH(k_joint_fix_f, ke, JGRID_T, 2, 1, 1, c.f, c.g, df, c.in_len, c.lab_len, grad_scale, jg, w);
-  RNNT_JOINT_DISPATCH(k_joint_fix_g, ke, JGRID_U, 2, 1, 1, c.f, c.g, dg, c.in_len, c.lab_len, grad_scale, jg, w);
+#define JBLOCKS_T(TT) (jg.B * ((((jg.maxT + (TT)-1) / (TT)) + 3) / 4))
+#define JBLOCKS_U(UU) (jg.B * ((((jg.maxU1 + (UU)-1) / (UU)) + 3) / 4))
+#define JGRID_FIX(TT) dim3((unsigned)(JBLOCKS_T(TT) + JBLOCKS_U(TT)))
+  const int fb4 = JBLOCKS_T(4), fb2 = JBLOCKS_T(2), fb1 = JBLOCKS_T(1);
+  const int f_blocks = ke <= 8 ? fb4 : ke == 16 ? fb2 : fb1;  // the tile heights RNNT_JOINT_DISPATCH picks below
+  RNNT_JOINT_DISPATCH(k_joint_fix, ke, JGRID_FIX, 2, 1, 1, c.f, c.g, df, dg, c.in_len, c.lab_len, grad_scale, jg, w,
+                      f_blocks);
   return launch_status();
 }
 
