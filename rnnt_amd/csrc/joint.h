@@ -25,7 +25,7 @@ namespace {
 // replace T*U*V exponentials.  Cells whose S underflows (maxima of f and g at
 // different v, far apart) are recomputed with the exact maximum, flagged, and
 // their gradient goes through the exponent-domain kernels further down.
-//   k_joint_prep    mf2, mg2 (base-2 row maxima), F, G
+//   k_joint_prep    mf2, mg2 (base-2 row maxima), F, G, the blank / label entries of every row
 //   k_joint_gather  blank / label parts of every cell's record
 //   k_joint_lse_mm  S -> records {lpb, lpl, log2 S}          (then k_sweep as usual)
 //   k_joint_coef    {c, pb, pl, label code} and C of every cell from alpha, beta, ll
@@ -74,7 +74,7 @@ __device__ __forceinline__ void jrow_load(const float* row, int V, int lane, flo
 // NIT > 0: the rows stay in registers between the two passes (NIT float4 per lane, V <= 256 * NIT).
 template <bool VEC4, int NIT>
 __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f, const float* __restrict__ g,
-                                                    JointGeom jg, Ws w) {
+                                                    const int32_t* __restrict__ labels, JointGeom jg, Ws w) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // first kernel of a forward: start the validation word and counters
     w.hdr->flags = 0;
     w.hdr->n_fallback = 0;
@@ -125,7 +125,21 @@ __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f,
     }
   }
   m = group_max<16>(m) * kLog2e;  // the 16 lanes of a row are one DPP row
-  if ((lane & 15) == 0 && row_ok) (isf ? w.mf2 + b * jg.maxT : w.mg2 + b * jg.maxU1)[row] = m;
+  if ((lane & 15) == 0 && row_ok) {
+    // besides the maximum: the blank entry of the row and, for g, the entry of the position's next label, so that
+    // k_joint_gather need not fetch them from a different 4*V-byte row for every cell
+    const float xb = __builtin_fmaf(src[jg.blank], kLog2e, -m);
+    if (isf) {
+      w.mf2[b * jg.maxT + row] = m;
+      w.fblank[b * jg.maxT + row] = xb;
+    } else {
+      int lab = row < jg.maxU1 - 1 ? labels[(size_t)b * (jg.maxU1 - 1) + row] : 0;
+      lab = (lab < 0 || lab >= V) ? 0 : lab;
+      w.mg2[b * jg.maxU1 + row] = m;
+      w.gblank[b * jg.maxU1 + row] = xb;
+      w.glabel[b * jg.maxU1 + row] = __builtin_fmaf(src[lab], kLog2e, -m);
+    }
+  }
   float* out = (isf ? w.Fp : w.Gp) + (size_t)b * R * w.Vp + tiled_off(row, e4, chunks);
   auto emit = [&](int c, const float (&x)[4]) {
     f4v y;
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f,
 // One thread per (b, t, u): the part of the cell's record that does not need the sum over V,
 //   {f2(t,blank) + g2(u,blank), f2(t,y_{u+1}) + g2(u,y_{u+1}), 0, 0}   (f2 = f*log2e - mf2, g2 likewise)
 // Entries that are no lattice cell get "log 0".
-__global__ __launch_bounds__(256) void k_joint_gather(const float* __restrict__ f, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void k_joint_gather(const float* __restrict__ f,
                                                       const int32_t* __restrict__ labels,
                                                       const int32_t* __restrict__ in_len,
                                                       const int32_t* __restrict__ lab_len, JointGeom jg, Ws w) {
@@ -164,16 +178,14 @@ __global__ __launch_bounds__(256) void k_joint_gather(const float* __restrict__ 
   float4 rc = make_float4(kNegF, kNegF, 0.f, 0.f);
   if (t < T && u <= U) {
     const float* fr = f + (size_t)b * jg.fstride + (size_t)t * jg.V;
-    const float* gr = g + ((size_t)b * jg.maxU1 + u) * jg.V;
-    const float mf2 = w.mf2[b * jg.maxT + t], mg2 = w.mg2[b * jg.maxU1 + u];
-    rc.x = __builtin_fmaf(fr[jg.blank], kLog2e, -mf2) + __builtin_fmaf(gr[jg.blank], kLog2e, -mg2);
+    rc.x = w.fblank[b * jg.maxT + t] + w.gblank[b * jg.maxU1 + u];
     if (u < U) {
       int lab = labels[(size_t)b * (jg.maxU1 - 1) + u];
       if (lab < 0 || lab >= jg.V) {
         atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
         lab = 0;
       }
-      rc.y = __builtin_fmaf(fr[lab], kLog2e, -mf2) + __builtin_fmaf(gr[lab], kLog2e, -mg2);
+      rc.y = __builtin_fmaf(fr[lab], kLog2e, -w.mf2[b * jg.maxT + t]) + w.glabel[b * jg.maxU1 + u];
     }
   }
   w.rec[((size_t)b * (jg.maxT + 2) + 1 + t) * jg.maxU1 + u] = rc;

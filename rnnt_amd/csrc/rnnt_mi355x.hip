@@ -334,8 +334,8 @@ int launch_joint_forward(const JointCall& c, float* costs, hipStream_t st) {
   const unsigned pgrid = (unsigned)((groups + 3) / 4);
 #define JOINT_PREP(NIT)                                                            \
   do {                                                                             \
-    if (rows16) k_joint_prep<true, NIT><<<pgrid, 256, 0, st>>>(c.f, c.g, jg, w);   \
-    else k_joint_prep<false, NIT><<<pgrid, 256, 0, st>>>(c.f, c.g, jg, w);         \
+    if (rows16) k_joint_prep<true, NIT><<<pgrid, 256, 0, st>>>(c.f, c.g, c.labels, jg, w);   \
+    else k_joint_prep<false, NIT><<<pgrid, 256, 0, st>>>(c.f, c.g, c.labels, jg, w);         \
   } while (0)
   if (w.Vp <= 256) JOINT_PREP(4);
   else if (w.Vp <= 1024) JOINT_PREP(16);
@@ -343,7 +343,7 @@ int launch_joint_forward(const JointCall& c, float* costs, hipStream_t st) {
   else JOINT_PREP(0);
 #undef JOINT_PREP
   const long long ncell = (long long)jg.B * jg.maxT * jg.maxU1;
-  k_joint_gather<<<(unsigned)((ncell + 255) / 256), 256, 0, st>>>(c.f, c.g, c.labels, c.in_len, c.lab_len, jg, w);
+  k_joint_gather<<<(unsigned)((ncell + 255) / 256), 256, 0, st>>>(c.f, c.labels, c.in_len, c.lab_len, jg, w);
   const int mt = w.Tp / 32;
   if (w.U1p <= 32)
     k_joint_lse_mm<1><<<mm_blocks(jg.B, mt, 1), 256, 0, st>>>(c.f, c.g, c.in_len, c.lab_len, jg, w);

@@ -43,6 +43,9 @@ struct Ws {
   // fused additive joint only:
   float* mf2;      // [B][maxT]  max_v f(b,t,v) * log2(e)
   float* mg2;      // [B][maxU1] max_v g(b,u,v) * log2(e)
+  float* fblank;   // [B][maxT]  f(b,t,blank)*log2(e) - mf2
+  float* gblank;   // [B][maxU1] g(b,u,blank)*log2(e) - mg2
+  float* glabel;   // [B][maxU1] g(b,u,y_{u+1})*log2(e) - mg2 (label clamped into [0,V); unused at u >= U_b)
   float4* coef;    // [B][maxT][maxU1] {c, pb, pl, label code} per cell (c = -inf: no gradient)
   // Operands of the three contractions, zero-padded, each stored in tiles of 32 rows x 8 columns
   // ([row tile][column chunk][32][8], see tiled_off) so that every wavefront load is a run of whole cache lines:
@@ -101,6 +104,9 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
   const size_t o_beta = take(sizeof(double) * plane);
   const size_t o_mf2 = joint ? take(sizeof(float) * (size_t)B * maxT) : 0;
   const size_t o_mg2 = joint ? take(sizeof(float) * (size_t)B * maxU1) : 0;
+  const size_t o_fblank = joint ? take(sizeof(float) * (size_t)B * maxT) : 0;
+  const size_t o_gblank = joint ? take(sizeof(float) * (size_t)B * maxU1) : 0;
+  const size_t o_glabel = joint ? take(sizeof(float) * (size_t)B * maxU1) : 0;
   const size_t o_coef = joint ? take(sizeof(float4) * (size_t)B * maxT * maxU1) : 0;
   const int Vp = V <= 32 ? 32 : V <= 64 ? 64 : (int)align_up((size_t)V, 128);
   const int U1p = (int)align_up((size_t)maxU1, 32), Tp = (int)align_up((size_t)maxT, 32);
@@ -122,6 +128,9 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
     w->beta = reinterpret_cast<double*>(p + o_beta);
     w->mf2 = joint ? reinterpret_cast<float*>(p + o_mf2) : nullptr;
     w->mg2 = joint ? reinterpret_cast<float*>(p + o_mg2) : nullptr;
+    w->fblank = joint ? reinterpret_cast<float*>(p + o_fblank) : nullptr;
+    w->gblank = joint ? reinterpret_cast<float*>(p + o_gblank) : nullptr;
+    w->glabel = joint ? reinterpret_cast<float*>(p + o_glabel) : nullptr;
     w->coef = joint ? reinterpret_cast<float4*>(p + o_coef) : nullptr;
     w->Fp = joint ? reinterpret_cast<float*>(p + o_Fp) : nullptr;
     w->Gp = joint ? reinterpret_cast<float*>(p + o_Gp) : nullptr;
