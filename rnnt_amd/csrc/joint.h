@@ -26,7 +26,7 @@ namespace {
 // different v, far apart) are recomputed with the exact maximum, flagged, and
 // their gradient goes through the exponent-domain kernels further down.
 //   k_joint_prep    mf2, mg2 (base-2 row maxima), F, G, the blank / label entries of every row
-//   k_joint_gather  blank / label parts of every cell's record
+//   k_joint_gather  f2(t, y_{u+1}) of every cell; final "log 0" records of everything that is no lattice cell
 //   k_joint_lse_mm  S -> records {lpb, lpl, log2 S}          (then k_sweep as usual)
 //   k_joint_coef    {c, pb, pl, label code} and C of every cell from alpha, beta, ll
 //   k_joint_df_mm, k_joint_dg_mm   the two gradient contractions
@@ -160,9 +160,9 @@ __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f,
   }
 }
 
-// One thread per (b, t, u): the part of the cell's record that does not need the sum over V,
-//   {f2(t,blank) + g2(u,blank), f2(t,y_{u+1}) + g2(u,y_{u+1}), 0, 0}   (f2 = f*log2e - mf2, g2 likewise)
-// Entries that are no lattice cell get "log 0".
+// One thread per (b, t, u).  A lattice cell gets flab(t,u) = f2(t, y_{u+1}) (f2 = f*log2e - mf2), the one part of its
+// record that has to be fetched per cell; k_joint_lse_mm puts the record together.  Entries that are no lattice
+// cell, and the guard frames, get their final "log 0" record here.
 __global__ __launch_bounds__(256) void k_joint_gather(const float* __restrict__ f,
                                                       const int32_t* __restrict__ labels,
                                                       const int32_t* __restrict__ in_len,
@@ -175,21 +175,21 @@ __global__ __launch_bounds__(256) void k_joint_gather(const float* __restrict__ 
   const int t = rem / jg.maxU1, u = rem - t * jg.maxU1;
   int T, U;
   utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
-  float4 rc = make_float4(kNegF, kNegF, 0.f, 0.f);
+  const float4 neg = make_float4(kNegF, kNegF, 0.f, 0.f);
   if (t < T && u <= U) {
-    const float* fr = f + (size_t)b * jg.fstride + (size_t)t * jg.V;
-    rc.x = w.fblank[b * jg.maxT + t] + w.gblank[b * jg.maxU1 + u];
+    float fl = 0.f;
     if (u < U) {
       int lab = labels[(size_t)b * (jg.maxU1 - 1) + u];
       if (lab < 0 || lab >= jg.V) {
         atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
         lab = 0;
       }
-      rc.y = __builtin_fmaf(fr[lab], kLog2e, -w.mf2[b * jg.maxT + t]) + w.glabel[b * jg.maxU1 + u];
+      fl = __builtin_fmaf(f[(size_t)b * jg.fstride + (size_t)t * jg.V + lab], kLog2e, -w.mf2[b * jg.maxT + t]);
     }
+    w.flab[i] = fl;
+  } else {
+    w.rec[((size_t)b * (jg.maxT + 2) + 1 + t) * jg.maxU1 + u] = neg;
   }
-  w.rec[((size_t)b * (jg.maxT + 2) + 1 + t) * jg.maxU1 + u] = rc;
-  const float4 neg = make_float4(kNegF, kNegF, 0.f, 0.f);
   if (t == 0) w.rec[((size_t)b * (jg.maxT + 2)) * jg.maxU1 + u] = neg;
   if (t == jg.maxT - 1) w.rec[((size_t)b * (jg.maxT + 2) + 1 + jg.maxT) * jg.maxU1 + u] = neg;
 }
@@ -291,18 +291,24 @@ __global__ __launch_bounds__(256) void k_joint_lse_mm(const float* __restrict__ 
     mfma_set(as[1], bs[1]);
     __builtin_amdgcn_sched_barrier(0);
   }
-  // Records of the tile's cells: {x - ls, y - ls, ls, flag}.  All 16 records of an MFMA tile are loaded first
-  // (lanes without a cell re-read a neighbouring one), then updated and stored, so that the memory round trips
-  // overlap.  Cells whose sum underflowed are left for the slow loop below.
+  // Records of the tile's cells: {f2(t,blank) + g2(u,blank) - ls, f2(t,y) + g2(u,y) - ls, ls, flag} with
+  // ls = log2 S.  The per-cell parts are all requested before the first record is stored (lanes without a cell
+  // re-read a neighbouring one).  Cells whose sum underflowed are left for the slow loop below.
   float4* frame0 = w.rec + ((size_t)b * (jg.maxT + 2) + 1) * jg.maxU1;
+  const float* fbl = w.fblank + (size_t)b * jg.maxT;
+  const float* flb = w.flab + (size_t)b * jg.maxT * jg.maxU1;
+  float fbv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) fbv[r] = fbl[min(t0 + mm_row(r, lane), T - 1)];
   unsigned badmask = 0;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int u = u0 + 32 * j + l32;
     const int uc = min(u, U);
-    float4 rc[16];
+    const float gb = w.gblank[b * jg.maxU1 + uc], gl = w.glabel[b * jg.maxU1 + uc];
+    float flv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rc[r] = frame0[(size_t)min(t0 + mm_row(r, lane), T - 1) * jg.maxU1 + uc];
+    for (int r = 0; r < 16; ++r) flv[r] = flb[(size_t)min(t0 + mm_row(r, lane), T - 1) * jg.maxU1 + uc];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int t = t0 + mm_row(r, lane);
@@ -312,12 +318,8 @@ __global__ __launch_bounds__(256) void k_joint_lse_mm(const float* __restrict__ 
       badmask |= bad ? (1u << (16 * j + r)) : 0u;
       if (valid && !bad) {
         const float ls = fast_log2(S);
-        float4 o = rc[r];
-        o.x -= ls;
-        o.y = (u < U) ? o.y - ls : kNegF;
-        o.z = ls;
-        o.w = 0.f;
-        frame0[(size_t)t * jg.maxU1 + u] = o;
+        frame0[(size_t)t * jg.maxU1 + u] =
+            make_float4((fbv[r] + gb) - ls, (u < U) ? (flv[r] + gl) - ls : kNegF, ls, 0.f);
       }
     }
   }
@@ -336,13 +338,9 @@ __global__ __launch_bounds__(256) void k_joint_lse_mm(const float* __restrict__ 
         if (lane == src) ls = e;
       }
       if (bad) {
-        float4* cell = frame0 + (size_t)t * jg.maxU1 + u;
-        float4 o = *cell;
-        o.x -= ls;
-        o.y = (u < U) ? o.y - ls : kNegF;
-        o.z = ls;
-        o.w = 1.f;
-        *cell = o;
+        const float xb = fbl[t] + w.gblank[b * jg.maxU1 + u];
+        const float xl = flb[(size_t)t * jg.maxU1 + u] + w.glabel[b * jg.maxU1 + u];
+        frame0[(size_t)t * jg.maxU1 + u] = make_float4(xb - ls, (u < U) ? xl - ls : kNegF, ls, 1.f);
         ++n_bad;
       }
     }

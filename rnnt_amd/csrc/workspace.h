@@ -46,6 +46,8 @@ struct Ws {
   float* fblank;   // [B][maxT]  f(b,t,blank)*log2(e) - mf2
   float* gblank;   // [B][maxU1] g(b,u,blank)*log2(e) - mg2
   float* glabel;   // [B][maxU1] g(b,u,y_{u+1})*log2(e) - mg2 (label clamped into [0,V); unused at u >= U_b)
+  float* flab;     // [B][maxT][maxU1] f(b,t,y_{u+1})*log2(e) - mf2 of the lattice cells.  Lives in the storage of Ctu:
+                   // the forward is done with it before a backward writes Ctu
   float4* coef;    // [B][maxT][maxU1] {c, pb, pl, label code} per cell (c = -inf: no gradient)
   // Operands of the three contractions, zero-padded, each stored in tiles of 32 rows x 8 columns
   // ([row tile][column chunk][32][8], see tiled_off) so that every wavefront load is a run of whole cache lines:
@@ -135,6 +137,7 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
     w->Fp = joint ? reinterpret_cast<float*>(p + o_Fp) : nullptr;
     w->Gp = joint ? reinterpret_cast<float*>(p + o_Gp) : nullptr;
     w->Ctu = joint ? reinterpret_cast<float*>(p + o_Ctu) : nullptr;
+    w->flab = w->Ctu;  // B*maxT*maxU1 <= B*Tp*U1p floats
     w->Cut = joint ? reinterpret_cast<float*>(p + o_Cut) : nullptr;
     w->head_of = joint ? reinterpret_cast<int*>(p + o_head) : nullptr;
     w->nxt = joint ? reinterpret_cast<int*>(p + o_nxt) : nullptr;
