@@ -349,7 +349,8 @@ __global__ __launch_bounds__(256) void k_joint_lse_mm(const float* __restrict__ 
 }
 
 // One block per (b, 8 frames, 32 label positions) of the padded lattice, one thread per cell: {c, s*pb, s*pl,
-// label code} (c = log2 gamma - log2 S, -inf when the cell is pruned) and C = s * 2^c for the contractions (0 where
+// label code} (c = log2 gamma - log2 S, -inf when the cell is pruned), the sums of s*pb and s*pl over the block's 8
+// frames, and C = s * 2^c for the contractions (0 where
 // pruned, flagged, or outside the lattice), written in both tiled orientations (the transposed one through LDS so
 // that both leave as runs of 32 bytes).
 __global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ labels,
@@ -357,13 +358,14 @@ __global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ 
                                                     const int32_t* __restrict__ lab_len,
                                                     const float* __restrict__ grad_scale, JointGeom jg, Ws w) {
   __shared__ float tile[8][33];
+  __shared__ float colp[2][8][33];
   const int ub = w.U1p >> 5, tb = w.Tp >> 3;
   const int b = blockIdx.x / (ub * tb);
   const int r = blockIdx.x - b * ub * tb;
   const int t0 = (r / ub) * 8, u0 = (r - (r / ub) * ub) * 32;
   const int tt = threadIdx.x >> 5, uu = threadIdx.x & 31;
   const int t = t0 + tt, u = u0 + uu;
-  float cm = 0.f, pbv = 0.f;
+  float cm = 0.f, pbv = 0.f, plv = 0.f;
   if (t < jg.maxT && u < jg.maxU1) {
     int T, U;
     utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ 
     cf.w = __int_as_float((raw.lab + 1) | (flagged ? kJointFlagBit : 0));
     if (live && !flagged) cm = sc * fast_exp2(cf.x);
     pbv = cf.y;
+    plv = cf.z;
     w.coef[((size_t)b * jg.maxT + t) * jg.maxU1 + u] = cf;
   }
   // the 32 positions of a frame in this block are one half wavefront: their blank terms, summed
@@ -385,9 +388,21 @@ __global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ 
   const size_t per_b = (size_t)w.Tp * w.U1p;
   w.Ctu[b * per_b + tiled_off(t, u, w.U1p >> 3)] = cm;
   tile[tt][uu] = cm;
+  colp[0][tt][uu] = pbv;
+  colp[1][tt][uu] = plv;
   __syncthreads();
   const int u2 = threadIdx.x >> 3, t2 = threadIdx.x & 7;
   w.Cut[b * per_b + tiled_off(u0 + u2, t0 + t2, w.Tp >> 3)] = tile[t2][u2];
+  // the block's 8 frames, summed per label position: k_joint_corr_g adds these up instead of re-reading every cell
+  if (threadIdx.x < 32) {
+    float sb = 0.f, sl = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sb += colp[0][i][uu];
+      sl += colp[1][i][uu];
+    }
+    w.colpart[((size_t)b * tb + (t0 >> 3)) * w.U1p + u] = make_float2(sb, sl);
+  }
 }
 
 // NT consecutive floats
@@ -739,11 +754,11 @@ __global__ __launch_bounds__(1024) void k_joint_corr_g(float* __restrict__ dg, c
   utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
   double sb = 0.0, sl = 0.0;
   if (u <= U) {
-    const float4* cfb = w.coef + (size_t)b * jg.maxT * jg.maxU1 + u;
-    for (int t = wv; t < T; t += 16) {
-      const float4 cf = cfb[(size_t)t * jg.maxU1];
-      sb += (double)cf.y;
-      sl += (double)cf.z;
+    const float2* cp = w.colpart + (size_t)b * (w.Tp >> 3) * w.U1p + u;
+    for (int t8 = wv; t8 < (T + 7) >> 3; t8 += 16) {  // cells past T_b contribute zeros
+      const float2 c2 = cp[(size_t)t8 * w.U1p];
+      sb += (double)c2.x;
+      sl += (double)c2.y;
     }
   }
   red[0][wv][lane] = sb;

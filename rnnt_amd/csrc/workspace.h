@@ -58,6 +58,7 @@ struct Ws {
   int* head_of;    // [B][Vp]       first position u whose target symbol is v (the blank's is U_b + 1), or -1
   int* nxt;        // [B][maxU1+2]  next position with the same target as position u, or -1
   float* rowpart;  // [B][Tp][U1p/32] sums of s*pb(t,u) over runs of 32 positions
+  float2* colpart; // [B][Tp/8][U1p] {sum of s*pb, sum of s*pl} over runs of 8 frames
   float* dgpart;   // [dg_split][B][maxU1][V] partial d g of each slice of the frames (only when dg_split > 1)
   int dg_split;    // slices the sum over frames of the d g contraction is cut into (1 = written straight to d g)
   int Vp, U1p, Tp; // padded extents: maxT and maxU1 rounded up to 32, V to 32 / 64 / a multiple of 128
@@ -119,6 +120,7 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
   const size_t o_head = joint ? take(sizeof(int) * (size_t)B * Vp) : 0;
   const size_t o_nxt = joint ? take(sizeof(int) * (size_t)B * (maxU1 + 2)) : 0;
   const size_t o_rowpart = joint ? take(sizeof(float) * (size_t)B * Tp * (U1p / 32)) : 0;
+  const size_t o_colpart = joint ? take(sizeof(float2) * (size_t)B * (Tp / 8) * U1p) : 0;
   const int dg_split = joint ? joint_dg_split(B, Tp, U1p, Vp) : 1;
   const size_t o_dgpart = dg_split > 1 ? take(sizeof(float) * (size_t)dg_split * B * maxU1 * V) : 0;
   if (w) {
@@ -142,6 +144,7 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
     w->head_of = joint ? reinterpret_cast<int*>(p + o_head) : nullptr;
     w->nxt = joint ? reinterpret_cast<int*>(p + o_nxt) : nullptr;
     w->rowpart = joint ? reinterpret_cast<float*>(p + o_rowpart) : nullptr;
+    w->colpart = joint ? reinterpret_cast<float2*>(p + o_colpart) : nullptr;
     w->dgpart = dg_split > 1 ? reinterpret_cast<float*>(p + o_dgpart) : nullptr;
     w->dg_split = dg_split;
     w->Vp = Vp; w->U1p = U1p; w->Tp = Tp;
