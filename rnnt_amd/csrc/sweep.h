@@ -27,7 +27,9 @@ namespace {
 // and was also slower (one column per lane 77 us against 61 us, two columns
 // 135 us against 76 us at T=500): the float64 ldexp/frexp steps cost more than
 // the transcendentals they replace.  Measured per diagonal: 109 ns with one
-// column per lane, 127 ns with two, 230 ns with four, 494 ns with eight.
+// column per lane, 127 ns with two, 230 ns with four, 494 ns with eight.  Cutting the loop from 30 to 24
+// instructions per diagonal (constant row stride, leaner address arithmetic, shifts that keep the boundary lane's
+// "log 0") brought 105 / 122 / 225 / 488 ns: the dependent chain, not instruction issue, sets the pace.
 // ---------------------------------------------------------------------------
 // lane i receives lane i-1's value; lane 0 receives `fill`
 __device__ __forceinline__ double lane_shift_up(double v, double fill) {
@@ -49,22 +51,25 @@ __device__ __forceinline__ double lane_shift_down(double v, double fill) {
 // Frames are clamped into the guard frames (-1 and maxT), columns beyond maxU1-1 read column maxU1-1 of the
 // guard frame; everything outside the lattice reads "log 0".  rec0 = record of frame -1, column 0.
 template <int K>
-__device__ __forceinline__ void load_lp_diag(const float4* rec0, int d, int maxT, int maxU1, const int (&ucol)[K],
-                                             const int (&uoff)[K], float (&pb)[K], float (&pl)[K]) {
+__device__ __forceinline__ void load_lp_diag(const float4* rec0, int d, int maxT, unsigned stride16,
+                                             const int (&ucol)[K], const unsigned (&uoff16)[K], float (&pb)[K],
+                                             float (&pl)[K]) {
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const int t1 = min(max(d - ucol[i], -1), maxT) + 1;                    // frame index incl. guards (v_med3_i32)
-    // 24-bit multiply-add (full rate; t1 <= maxT + 1 < 2^24, maxU1 <= 1024), 32-bit byte offset from a uniform base
-    const unsigned off = __umul24((unsigned)t1, (unsigned)maxU1) + (unsigned)uoff[i];  // uoff = min(u, maxU1-1) or a guard slot
-    const float2 q = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rec0) + (size_t)(off << 4));
+    // frame index incl. guards: (d - u) + 1 clamped into [0, maxT + 1]; subtract, max, min, one 24-bit multiply-add
+    // (t1 <= maxT + 1 < 2^24, stride16 = 16 * maxU1 <= 2^14) giving a 32-bit byte offset from a uniform base
+    const int t1 = min(max(d + 1 - ucol[i], 0), maxT + 1);
+    const unsigned off = __umul24((unsigned)t1, stride16) + uoff16[i];  // uoff16 = 16 * min(u, maxU1-1) or a guard slot
+    const float2 q = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rec0) + off);
     pb[i] = q.x;
     pl[i] = q.y;
   }
 }
 
 template <int K>
-__device__ __forceinline__ void store_row(double* base, int row, unsigned U1s, int u0, const double (&v)[K]) {
-  double* p = base + ((unsigned)row * U1s + (unsigned)u0);
+__device__ __forceinline__ void store_row(double* base, int row, int u0, const double (&v)[K]) {
+  double* p = base + ((unsigned)row * (64u * K) + (unsigned)u0);  // row stride 64 * K: a constant, so that the rows of
+                                                                  // an unrolled group differ by immediate offsets
   if constexpr (K == 1) {
     p[0] = v[0];
   } else {
@@ -98,54 +103,57 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
     return;
   }
   const int T = Traw, U = Uraw;
-  const unsigned U1s = (unsigned)w.U1s;
+  constexpr unsigned U1s = 64u * K;  // = w.U1s (the launch picks K from the same rule as the layout)
   const size_t plane = (size_t)b * w.D * U1s;
   const float4* rec0 = w.rec + (size_t)b * (maxT + 2) * maxU1;  // frame -1 (guard), column 0
   const int u0 = lane * K;
   const int dlast = T - 1 + U;
 
   // columns beyond maxU1-1 have no record: they read the guard frame (frame index forced to -1 by a huge column)
-  int ucol[K], uoff[K];
+  int ucol[K];
+  unsigned uoff16[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const int u = u0 + i;
     const bool has = u < maxU1;
     ucol[i] = has ? u : (1 << 28);
-    uoff[i] = has ? u : 0;
+    uoff16[i] = has ? 16u * (unsigned)u : 0u;
   }
+  const unsigned stride16 = 16u * (unsigned)maxU1;
 
   if (dir == 0) {
     double* alpha = w.alpha + plane;
     double a[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) a[i] = (u0 + i == 0) ? 0.0 : kNeg;
-    store_row<K>(alpha, 0, U1s, u0, a);
+    store_row<K>(alpha, 0, u0, a);
+    double from_left = kNeg;
     // one diagonal: a <- alpha(d) from alpha(d-1) and the log-probs of diagonal d-1
     auto step = [&](int d, const float (&pb)[K], const float (&pl)[K]) {
       double el[K];
 #pragma unroll
       for (int i = 0; i < K; ++i) el[i] = a[i] + (double)pl[i];
-      const double from_left = lane_shift_up(el[K - 1], kNeg);
+      from_left = lane_shift_up(el[K - 1], from_left);  // lane 0 keeps its "log 0": no constant to re-load
 #pragma unroll
       for (int i = 0; i < K; ++i) a[i] = log2_add(a[i] + (double)pb[i], (i == 0) ? from_left : el[i - 1]);
-      store_row<K>(alpha, d, U1s, u0, a);
+      store_row<K>(alpha, d, u0, a);
     };
     int d = 1;
     // remainder first, so that the pipelined loop below runs whole groups of P
     for (const int rem = dlast % P; d <= rem; ++d) {
       float pb[K], pl[K];
-      load_lp_diag<K>(rec0, d - 1, maxT, maxU1, ucol, uoff, pb, pl);
+      load_lp_diag<K>(rec0, d - 1, maxT, stride16, ucol, uoff16, pb, pl);
       step(d, pb, pl);
     }
     if (d <= dlast) {
       float pb[P][K], pl[P][K];
 #pragma unroll
-      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec0, d - 1 + p, maxT, maxU1, ucol, uoff, pb[p], pl[p]);
+      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec0, d - 1 + p, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
       for (; d <= dlast; d += P) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           step(d + p, pb[p], pl[p]);
-          load_lp_diag<K>(rec0, d + p - 1 + P, maxT, maxU1, ucol, uoff, pb[p], pl[p]);
+          load_lp_diag<K>(rec0, d + p - 1 + P, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
           __builtin_amdgcn_sched_barrier(0);  // keep the refill P diagonals ahead of its use
         }
       }
@@ -165,32 +173,33 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
     double bt[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) bt[i] = (u0 + i == U) ? 0.0 : kNeg;
+    double from_right = kNeg;
     // one diagonal: bt <- beta(d) from beta(d+1) and the log-probs of diagonal d
     auto step = [&](int d, const float (&pb)[K], const float (&pl)[K]) {
-      const double from_right = lane_shift_down(bt[0], kNeg);
+      from_right = lane_shift_down(bt[0], from_right);  // lane 63 keeps its "log 0"
       double nb[K];
 #pragma unroll
       for (int i = 0; i < K; ++i)
         nb[i] = log2_add(bt[i] + (double)pb[i], ((i == K - 1) ? from_right : bt[i + 1]) + (double)pl[i]);
 #pragma unroll
       for (int i = 0; i < K; ++i) bt[i] = nb[i];
-      store_row<K>(beta, d, U1s, u0, bt);
+      store_row<K>(beta, d, u0, bt);
     };
     int d = dlast;
     for (int rem = (dlast + 1) % P; rem > 0; --rem, --d) {
       float pb[K], pl[K];
-      load_lp_diag<K>(rec0, d, maxT, maxU1, ucol, uoff, pb, pl);
+      load_lp_diag<K>(rec0, d, maxT, stride16, ucol, uoff16, pb, pl);
       step(d, pb, pl);
     }
     if (d >= 0) {
       float pb[P][K], pl[P][K];
 #pragma unroll
-      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec0, d - p, maxT, maxU1, ucol, uoff, pb[p], pl[p]);
+      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec0, d - p, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
       for (; d >= 0; d -= P) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           step(d - p, pb[p], pl[p]);
-          load_lp_diag<K>(rec0, d - p - P, maxT, maxU1, ucol, uoff, pb[p], pl[p]);
+          load_lp_diag<K>(rec0, d - p - P, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
