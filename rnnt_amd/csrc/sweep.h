@@ -88,7 +88,11 @@ template <int K>
 __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, const int32_t* __restrict__ in_len,
                                               const int32_t* __restrict__ lab_len, int B, int maxT, int maxU1,
                                               int b0) {
-  constexpr int P = 4;  // diagonals of log-probs kept in flight ahead of the dependent chain
+  // Diagonals of log-probs kept in flight ahead of the dependent chain.  A diagonal's loads take ~0.4 us to come
+  // back (most hit the vector cache, every eighth goes further) while its arithmetic takes 40-60 ns per column:
+  // with 4 in flight the loop waited for memory (109 / 127 ns per diagonal with one / two columns per lane);
+  // 16 / 8 bring 60 / 92 ns.  (24 and 12: 64 / 94 ns.  Wider lanes are bound by their arithmetic: no change.)
+  constexpr int P = K == 1 ? 16 : K == 2 ? 8 : 4;
   const int b = b0 + (blockIdx.x >> 1);
   const int dir = blockIdx.x & 1;
   const int lane = threadIdx.x;
@@ -139,14 +143,18 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
       store_row<K>(alpha, d, u0, a);
     };
     int d = 1;
-    // remainder first, so that the pipelined loop below runs whole groups of P
-    for (const int rem = dlast % P; d <= rem; ++d) {
-      float pb[K], pl[K];
-      load_lp_diag<K>(rec0, d - 1, maxT, stride16, ucol, uoff16, pb, pl);
-      step(d, pb, pl);
-    }
+    float pb[P][K], pl[P][K];
+    // remainder first (its loads all requested before the first step), so that the pipelined loop below runs
+    // whole groups of P
+    const int rem = dlast % P;
+#pragma unroll
+    for (int p = 0; p < P - 1; ++p)
+      if (p < rem) load_lp_diag<K>(rec0, p, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
+#pragma unroll
+    for (int p = 0; p < P - 1; ++p)
+      if (p < rem) step(1 + p, pb[p], pl[p]);
+    d += rem;
     if (d <= dlast) {
-      float pb[P][K], pl[P][K];
 #pragma unroll
       for (int p = 0; p < P; ++p) load_lp_diag<K>(rec0, d - 1 + p, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
       for (; d <= dlast; d += P) {
@@ -186,13 +194,16 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
       store_row<K>(beta, d, u0, bt);
     };
     int d = dlast;
-    for (int rem = (dlast + 1) % P; rem > 0; --rem, --d) {
-      float pb[K], pl[K];
-      load_lp_diag<K>(rec0, d, maxT, stride16, ucol, uoff16, pb, pl);
-      step(d, pb, pl);
-    }
+    float pb[P][K], pl[P][K];
+    const int rem = (dlast + 1) % P;
+#pragma unroll
+    for (int p = 0; p < P - 1; ++p)
+      if (p < rem) load_lp_diag<K>(rec0, dlast - p, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
+#pragma unroll
+    for (int p = 0; p < P - 1; ++p)
+      if (p < rem) step(dlast - p, pb[p], pl[p]);
+    d -= rem;
     if (d >= 0) {
-      float pb[P][K], pl[P][K];
 #pragma unroll
       for (int p = 0; p < P; ++p) load_lp_diag<K>(rec0, d - p, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
       for (; d >= 0; d -= P) {
