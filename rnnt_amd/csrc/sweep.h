@@ -92,6 +92,10 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
   // back (most hit the vector cache, every eighth goes further) while its arithmetic takes 40-60 ns per column:
   // with 4 in flight the loop waited for memory (109 / 127 ns per diagonal with one / two columns per lane);
   // 16 / 8 bring 60 / 92 ns.  (24 and 12: 64 / 94 ns.  Wider lanes are bound by their arithmetic: no change.)
+  // Measured and dropped: a one-instruction clamp (v_med3_i32), a running frame index and scalar-base stores cut
+  // two columns per lane from 42 to 37 instructions per diagonal without changing its 92-96 ns; tools/lat_bench.hip
+  // puts an independent instruction of this mix at 2-2.3 ns and v_exp_f32 / v_log_f32 at 3.8 ns on one wavefront,
+  // i.e. ~45 ns per column for the arithmetic alone.
   constexpr int P = K == 1 ? 16 : K == 2 ? 8 : 4;
   const int b = b0 + (blockIdx.x >> 1);
   const int dir = blockIdx.x & 1;

@@ -1,57 +1,68 @@
-// Latency of dependent VALU operations on one wavefront (the lattice sweep is one long dependent chain per
-// wavefront): N iterations of a chain of a single operation kind, timed with HIP events.
+// Latency and issue cost of the vector operations the lattice sweep is made of, on one wavefront (the sweep is one
+// wavefront per utterance and direction).  "dep": a chain of dependent operations of one kind; "ind": eight
+// independent chains interleaved (cost per operation when the pipeline is kept full).
 //   hipcc --offload-arch=gfx950 -O3 -o tools/lat_bench tools/lat_bench.hip && tools/lat_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
-constexpr int kIters = 1 << 20;
+constexpr int kIters = 1 << 18;
 
 template <int OP>
-__global__ __launch_bounds__(64) void k_chain(double* out, double seed, float fseed) {
-  double x = seed + threadIdx.x;
-  float f = fseed + threadIdx.x * 1e-3f;
-  int lo = threadIdx.x;
-#pragma unroll 1
-  for (int i = 0; i < kIters; i += 8) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (OP == 0) x = x + seed;                                                   // v_add_f64
-      if (OP == 1) x = fmax(x * 1.0000001, seed);                                  // v_mul_f64 + v_max_f64
-      if (OP == 2) x = (double)((float)x) + 0.0;                                   // cvt f64->f32, cvt f32->f64 (+ add folded?)
-      if (OP == 3) f = __builtin_amdgcn_exp2f(-f);                                 // v_exp_f32
-      if (OP == 4) f = __builtin_amdgcn_logf(f + 2.0f);                            // v_add_f32 + v_log_f32
-      if (OP == 5) f = f + fseed;                                                  // v_add_f32
-      if (OP == 6) lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // v_mov_b32_dpp wave_shr:1
-      if (OP == 7) lo = __builtin_amdgcn_update_dpp(lo, lo, 0x111, 0xf, 0xf, false);  // v_mov_b32_dpp row_shr:1
-      if (OP == 8) f = (float)((double)f);                                         // cvt f32->f64, cvt f64->f32
-    }
-  }
-  out[threadIdx.x] = x + f + lo;
+__device__ __forceinline__ void op(double& x, float& f, int& lo, double seed, float fseed) {
+  if (OP == 0) x = x + seed;                                                     // v_add_f64
+  if (OP == 1) x = fmax(x, seed) ;                                               // v_max_f64
+  if (OP == 2) { f = (float)x; x = (double)f; }                                  // v_cvt_f32_f64 + v_cvt_f64_f32
+  if (OP == 3) f = __builtin_amdgcn_exp2f(-f);                                   // v_exp_f32
+  if (OP == 4) f = __builtin_amdgcn_logf(f);                                     // v_log_f32
+  if (OP == 5) f = f + fseed;                                                    // v_add_f32
+  if (OP == 6) lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false); // v_mov_b32_dpp wave_shr:1
 }
 
-template <int OP>
+template <int OP, int NCH>
+__global__ __launch_bounds__(64) void k_chain(double* out, double seed, float fseed) {
+  double x[NCH];
+  float f[NCH];
+  int lo[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) { x[c] = seed + threadIdx.x + c; f[c] = fseed + threadIdx.x * 1e-3f + c; lo[c] = threadIdx.x + c; }
+#pragma unroll 1
+  for (int i = 0; i < kIters; i += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) op<OP>(x[c], f[c], lo[c], seed, fseed);
+    if (OP == 2) {  // keep the conversions from being folded away
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(x[c]));
+    }
+  }
+  double s = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) s += x[c] + f[c] + lo[c];
+  out[threadIdx.x] = s;
+}
+
+template <int OP, int NCH>
 float run(double* d) {
   hipEvent_t a, b;
-  hipEventCreate(&a); hipEventCreate(&b);
-  k_chain<OP><<<1, 64>>>(d, 1.0, 0.5f);
-  hipEventRecord(a);
-  k_chain<OP><<<1, 64>>>(d, 1.0, 0.5f);
-  hipEventRecord(b);
-  hipEventSynchronize(b);
-  float ms; hipEventElapsedTime(&ms, a, b);
-  return ms * 1e6f / kIters;  // ns per iteration
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  k_chain<OP, NCH><<<1, 64>>>(d, 1.0, 0.5f);
+  (void)hipEventRecord(a);
+  k_chain<OP, NCH><<<1, 64>>>(d, 1.0, 0.5f);
+  (void)hipEventRecord(b);
+  (void)hipEventSynchronize(b);
+  float ms; (void)hipEventElapsedTime(&ms, a, b);
+  return ms * 1e6f / kIters / NCH;  // ns per operation
 }
 
 int main() {
-  double* d; hipMalloc(&d, 64 * sizeof(double));
-  printf("add_f64            %.2f ns\n", run<0>(d));
-  printf("mul_f64+max_f64    %.2f ns\n", run<1>(d));
-  printf("cvt64->32->64(+add) %.2f ns\n", run<2>(d));
-  printf("exp_f32            %.2f ns\n", run<3>(d));
-  printf("add_f32+log_f32    %.2f ns\n", run<4>(d));
-  printf("add_f32            %.2f ns\n", run<5>(d));
-  printf("dpp wave_shr:1     %.2f ns\n", run<6>(d));
-  printf("dpp row_shr:1      %.2f ns\n", run<7>(d));
-  printf("cvt32->64->32      %.2f ns\n", run<8>(d));
+  double* d; (void)hipMalloc(&d, 64 * sizeof(double));
+  printf("%-28s dep %6.2f ns   ind %6.2f ns\n", "v_add_f64", run<0, 1>(d), run<0, 8>(d));
+  printf("%-28s dep %6.2f ns   ind %6.2f ns\n", "v_max_f64", run<1, 1>(d), run<1, 8>(d));
+  printf("%-28s dep %6.2f ns   ind %6.2f ns  (two operations)\n", "cvt f64->f32->f64", run<2, 1>(d), run<2, 8>(d));
+  printf("%-28s dep %6.2f ns   ind %6.2f ns\n", "v_exp_f32", run<3, 1>(d), run<3, 8>(d));
+  printf("%-28s dep %6.2f ns   ind %6.2f ns\n", "v_log_f32", run<4, 1>(d), run<4, 8>(d));
+  printf("%-28s dep %6.2f ns   ind %6.2f ns\n", "v_add_f32", run<5, 1>(d), run<5, 8>(d));
+  printf("%-28s dep %6.2f ns   ind %6.2f ns\n", "v_mov_b32_dpp wave_shr:1", run<6, 1>(d), run<6, 8>(d));
   return 0;
 }
