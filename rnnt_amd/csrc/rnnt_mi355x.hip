@@ -165,7 +165,7 @@ SmallGeom small_geom(const Call& c, int* blocks) {
   long long want = (g.ntiles_full + kSmallWaves - 1) / kSmallWaves;
   // persistent grid, exactly one resident round: tiles are dealt round-robin to the waves.  Residency per CU is
   // limited by LDS (160 KiB / tile bytes per block) and by registers (6 blocks of two waves).
-  const long long lds_bytes = 16LL * 16 * c.V * kSmallWaves;
+  const long long lds_bytes = 16LL * small_lds_f4(c.V) * kSmallWaves;
   long long per_cu = (160LL * 1024) / lds_bytes;
   if (per_cu > 6) per_cu = 6;
   if (per_cu < 1) per_cu = 1;
@@ -182,11 +182,12 @@ void launch_lse(const Call& c, int b0, int nb, hipStream_t st) {
   if (b0 == 0 && nb == c.B && use_small(c, c.logits)) {
     int blocks;
     const SmallGeom g = small_geom(c, &blocks);
-    const size_t lds = sizeof(float4) * 16 * (size_t)c.V * kSmallWaves;
+    const size_t lds = sizeof(float4) * (size_t)small_lds_f4(c.V) * kSmallWaves;
     const float* x0 = c.logits - (size_t)c.t_off * c.maxU1 * c.V;  // frame 0 of the uncropped tensor
-    if (c.V % 4 == 0) k_lse_small<4><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
-    else if (c.V % 2 == 0) k_lse_small<2><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
-    else k_lse_small<1><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
+    if (small_pad4(c.V)) k_lse_small<4, true><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
+    else if (c.V % 4 == 0) k_lse_small<4, false><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
+    else if (c.V % 2 == 0) k_lse_small<2, false><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
+    else k_lse_small<1, false><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
     return;
   }
   const RowCfg cfg = sub_cfg(c, c.logits, b0, nb);
@@ -209,13 +210,14 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
   if (b0 == 0 && nb == c.B && use_small(c, c.grad)) {
     int blocks;
     const SmallGeom g = small_geom(c, &blocks);
-    const size_t lds = sizeof(float4) * 16 * (size_t)c.V * kSmallWaves;
+    const size_t lds = sizeof(float4) * (size_t)small_lds_f4(c.V) * kSmallWaves;
     const size_t skip = (size_t)c.t_off * c.maxU1 * c.V;  // the cropped frames are rows without a cell: zero-filled
     const float* x0 = c.logits - skip;
     float* g0 = c.grad - skip;
-    if (c.V % 4 == 0) k_grad_small<4><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
-    else if (c.V % 2 == 0) k_grad_small<2><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
-    else k_grad_small<1><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
+    if (small_pad4(c.V)) k_grad_small<4, true><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
+    else if (c.V % 4 == 0) k_grad_small<4, false><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
+    else if (c.V % 2 == 0) k_grad_small<2, false><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
+    else k_grad_small<1, false><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
     return;
   }
   if (c.t_off > 0 && b0 == 0) {  // gradient of the cropped frames

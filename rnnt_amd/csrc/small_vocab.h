@@ -25,6 +25,16 @@ constexpr int kSmallBlock = 128;                // two wavefronts, each with its
 constexpr int kSmallWaves = kSmallBlock / 64;
 constexpr int kSmallNld = kSmallMaxV * 64 / 4 / 64;  // float4 loads per lane per tile (max)
 
+// A tile lives in LDS row by row and every lane walks its own row, so the row stride decides the bank pattern.
+// At V = 64 the stride is 256 bytes: all lanes of a 128-bit access on the same four banks (measured 3.2 / 4.4 TB/s
+// for the two passes where V = 62 reaches 4.9 / 6.0).  Those kernels are instantiated with PAD: one float4 of
+// padding per row, 17 float4 of stride, which spreads 16 lanes over all 64 banks (5.0 / 5.9 TB/s).  Padding the
+// other even-float4 row lengths (V = 16 ... 56) measured slower in the gradient pass: the address arithmetic costs
+// 14 registers and with them a resident wavefront per SIMD, more than their two-way conflicts do.
+__host__ __device__ inline int small_pad4(int V) { return V == 64 ? 1 : 0; }
+// float4 slots of a wave's LDS tile
+__host__ __device__ inline int small_lds_f4(int V) { return 16 * V + 64 * small_pad4(V); }
+
 struct SmallGeom {
   int B, maxT, maxU1, V, blank;
   int frames;            // frames per utterance in memory = t_off + maxT
@@ -92,7 +102,7 @@ __device__ __forceinline__ void small_write_record(const Ws& w, const SmallGeom&
   if (t == g.maxT - 1) (frame0 + (size_t)g.maxT * g.maxU1)[u] = neg;
 }
 
-template <int VEC>
+template <int VEC, bool PAD>
 __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restrict__ x,
                                                            const int32_t* __restrict__ labels,
                                                            const int32_t* __restrict__ in_len,
@@ -101,8 +111,10 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int V = g.V;
   const int tile_f4 = 16 * V;  // 64 rows * V floats / 4
-  float4* tile4 = lds4 + wv * tile_f4;
-  const float* rowp = reinterpret_cast<const float*>(tile4) + lane * V;
+  float4* tile4 = lds4 + wv * (tile_f4 + (PAD ? 64 : 0));
+  const float* rowp = reinterpret_cast<const float*>(tile4) + lane * (V + (PAD ? 4 : 0));
+  // float4 number q of the tile in memory order -> its LDS slot; PAD (V = 64, 16 float4 per row): q + row of q
+  auto slot = [&](int q) { return PAD ? q + (q >> 4) : q; };
   const int gw = blockIdx.x * kSmallWaves + wv, nw = gridDim.x * kSmallWaves;
   const f4v* x4 = reinterpret_cast<const f4v*>(x);
 
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
 #pragma unroll
       for (int i = 0; i < kSmallNld; ++i) {
         const int q = lane + 64 * i;
-        if (q < tile_f4) tile4[q] = make_float4(st[i].x, st[i].y, st[i].z, st[i].w);
+        if (q < tile_f4) tile4[slot(q)] = make_float4(st[i].x, st[i].y, st[i].z, st[i].w);
       }
     }
     const int cb = b, ct = t, cu = u, cU = U;
@@ -271,7 +283,7 @@ __device__ __forceinline__ float small_row_grad(const float* src, float* dst, in
   return sq;
 }
 
-template <int VEC>
+template <int VEC, bool PAD>
 __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, float* grad,
                                                             const int32_t* __restrict__ labels,
                                                             const int32_t* __restrict__ in_len,
@@ -281,8 +293,9 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int V = g.V;
   const int tile_f4 = 16 * V;
-  float4* tile4 = lds4 + wv * tile_f4;
-  float* rowp = reinterpret_cast<float*>(tile4) + lane * V;
+  float4* tile4 = lds4 + wv * (tile_f4 + (PAD ? 64 : 0));
+  float* rowp = reinterpret_cast<float*>(tile4) + lane * (V + (PAD ? 4 : 0));
+  auto slot = [&](int q) { return PAD ? q + (q >> 4) : q; };  // see k_lse_small
   const int gw = blockIdx.x * kSmallWaves + wv, nw = gridDim.x * kSmallWaves;
   const f4v* x4 = reinterpret_cast<const f4v*>(x);
   f4v* g4 = reinterpret_cast<f4v*>(grad);
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
 #pragma unroll
     for (int i = 0; i < kSmallNld; ++i) {
       const int q = lane + 64 * i;
-      if (chunk_needed(active, i) && q < tile_f4) tile4[q] = make_float4(st[i].x, st[i].y, st[i].z, st[i].w);
+      if (chunk_needed(active, i) && q < tile_f4) tile4[slot(q)] = make_float4(st[i].x, st[i].y, st[i].z, st[i].w);
     }
     const float4 ccf = cf;
     const float csc = sc;
@@ -365,7 +378,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
     for (int i = 0; i < kSmallNld; ++i) {
       const int q = lane + 64 * i;
       if (q < tile_f4) {
-        const float4 o = tile4[q];
+        const float4 o = tile4[slot(q)];
         f4v ov = {o.x, o.y, o.z, o.w};
         __builtin_nontemporal_store(ov, dst + q);
       }

@@ -5,7 +5,7 @@ import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rnnt_amd import _lib
 L = _lib.lib(); dev = torch.device("cuda:0"); p = lambda t: ctypes.c_void_p(t.data_ptr())
-B, T, V = 32, 500, 8
+B, T, V = (int(sys.argv[1]) if len(sys.argv) > 1 else 32), 500, 8   # usage: sweep_probe.py [B]
 for U in (63, 100, 199, 399):
     x = torch.randn(B, T, U + 1, V, device=dev)
     lab = torch.randint(1, V, (B, U), device=dev, dtype=torch.int32)
