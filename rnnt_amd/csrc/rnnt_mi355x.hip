@@ -178,16 +178,43 @@ SmallGeom small_geom(const Call& c, int* blocks) {
   return g;
 }
 
+// Instantiation of a small-vocabulary kernel for V: vector width of the row loops, LDS padding mode, staging depth.
+// Tiles above 64 KiB per block need the dynamic-LDS limit raised (once per instantiation).
+#define RNNT_SMALL_LAUNCH(KERNEL, VEC, PAD, NLD, blocks, lds, st, ...)                                          \
+  do {                                                                                                          \
+    if ((lds) > 48 * 1024) {                                                                                    \
+      static bool raised = false;                                                                               \
+      if (!raised) {                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<VEC, PAD, NLD>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                       \
+        raised = true;                                                                                          \
+      }                                                                                                         \
+    }                                                                                                           \
+    KERNEL<VEC, PAD, NLD><<<blocks, kSmallBlock, lds, st>>>(__VA_ARGS__);                                       \
+  } while (0)
+#define RNNT_SMALL_DISPATCH(KERNEL, V, blocks, lds, st, ...)                                                    \
+  do {                                                                                                          \
+    const int pm = small_pad_mode(V);                                                                           \
+    if ((V) <= 64) {                                                                                            \
+      if (pm == 1) RNNT_SMALL_LAUNCH(KERNEL, 4, 1, 16, blocks, lds, st, __VA_ARGS__);                           \
+      else if ((V) % 4 == 0) RNNT_SMALL_LAUNCH(KERNEL, 4, 0, 16, blocks, lds, st, __VA_ARGS__);                 \
+      else if ((V) % 2 == 0) RNNT_SMALL_LAUNCH(KERNEL, 2, 0, 16, blocks, lds, st, __VA_ARGS__);                 \
+      else RNNT_SMALL_LAUNCH(KERNEL, 1, 0, 16, blocks, lds, st, __VA_ARGS__);                                   \
+    } else {                                                                                                    \
+      if (pm == 2) RNNT_SMALL_LAUNCH(KERNEL, 4, 2, 32, blocks, lds, st, __VA_ARGS__);                           \
+      else if ((V) % 4 == 0) RNNT_SMALL_LAUNCH(KERNEL, 4, 0, 32, blocks, lds, st, __VA_ARGS__);                 \
+      else if ((V) % 2 == 0) RNNT_SMALL_LAUNCH(KERNEL, 2, 0, 32, blocks, lds, st, __VA_ARGS__);                 \
+      else RNNT_SMALL_LAUNCH(KERNEL, 1, 0, 32, blocks, lds, st, __VA_ARGS__);                                   \
+    }                                                                                                           \
+  } while (0)
+
 void launch_lse(const Call& c, int b0, int nb, hipStream_t st) {
   if (b0 == 0 && nb == c.B && use_small(c, c.logits)) {
     int blocks;
     const SmallGeom g = small_geom(c, &blocks);
     const size_t lds = sizeof(float4) * (size_t)small_lds_f4(c.V) * kSmallWaves;
     const float* x0 = c.logits - (size_t)c.t_off * c.maxU1 * c.V;  // frame 0 of the uncropped tensor
-    if (small_pad4(c.V)) k_lse_small<4, true><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
-    else if (c.V % 4 == 0) k_lse_small<4, false><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
-    else if (c.V % 2 == 0) k_lse_small<2, false><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
-    else k_lse_small<1, false><<<blocks, kSmallBlock, lds, st>>>(x0, c.labels, c.in_len, c.lab_len, g, c.w);
+    RNNT_SMALL_DISPATCH(k_lse_small, c.V, blocks, lds, st, x0, c.labels, c.in_len, c.lab_len, g, c.w);
     return;
   }
   const RowCfg cfg = sub_cfg(c, c.logits, b0, nb);
@@ -214,10 +241,7 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
     const size_t skip = (size_t)c.t_off * c.maxU1 * c.V;  // the cropped frames are rows without a cell: zero-filled
     const float* x0 = c.logits - skip;
     float* g0 = c.grad - skip;
-    if (small_pad4(c.V)) k_grad_small<4, true><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
-    else if (c.V % 4 == 0) k_grad_small<4, false><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
-    else if (c.V % 2 == 0) k_grad_small<2, false><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
-    else k_grad_small<1, false><<<blocks, kSmallBlock, lds, st>>>(x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
+    RNNT_SMALL_DISPATCH(k_grad_small, c.V, blocks, lds, st, x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
     return;
   }
   if (c.t_off > 0 && b0 == 0) {  // gradient of the cropped frames

@@ -20,20 +20,25 @@ namespace {
 // tile leave as one contiguous 1 KiB store.  The next tile's loads are in
 // flight while the current one is processed.
 // ---------------------------------------------------------------------------
-constexpr int kSmallMaxV = 64;
+constexpr int kSmallMaxV = 128;
 constexpr int kSmallBlock = 128;                // two wavefronts, each with its own LDS tile
 constexpr int kSmallWaves = kSmallBlock / 64;
-constexpr int kSmallNld = kSmallMaxV * 64 / 4 / 64;  // float4 loads per lane per tile (max)
+// float4 loads per lane per tile: the kernels are instantiated with NLD = 16 (V <= 64) and 32 (V <= 128)
+__host__ __device__ inline int small_nld(int V) { return V <= 64 ? 16 : 32; }
 
 // A tile lives in LDS row by row and every lane walks its own row, so the row stride decides the bank pattern.
 // At V = 64 the stride is 256 bytes: all lanes of a 128-bit access on the same four banks (measured 3.2 / 4.4 TB/s
-// for the two passes where V = 62 reaches 4.9 / 6.0).  Those kernels are instantiated with PAD: one float4 of
-// padding per row, 17 float4 of stride, which spreads 16 lanes over all 64 banks (5.0 / 5.9 TB/s).  Padding the
-// other even-float4 row lengths (V = 16 ... 56) measured slower in the gradient pass: the address arithmetic costs
-// 14 registers and with them a resident wavefront per SIMD, more than their two-way conflicts do.
-__host__ __device__ inline int small_pad4(int V) { return V == 64 ? 1 : 0; }
+// for the two passes where V = 62 reaches 4.9 / 6.0).  PAD = 1 (V = 64): one float4 of padding per row, 17 float4
+// of stride, which spreads 16 lanes over all 64 banks (4.9 / 6.2 TB/s).  Padding the other even-float4 row lengths
+// up to 64 measured slower in the gradient pass: the address arithmetic costs 14 registers and with them a resident
+// wavefront per SIMD, more than their two-way conflicts do.  Above 64 residency is set by LDS alone (a tile is
+// 17-34 KiB), registers are free: PAD = 2 pads every row of an even number of float4 (general row length).
+__host__ __device__ inline int small_pad_mode(int V) {
+  if (V % 4 != 0 || (V / 4) % 2 != 0) return 0;
+  return V == 64 ? 1 : V > 64 ? 2 : 0;
+}
 // float4 slots of a wave's LDS tile
-__host__ __device__ inline int small_lds_f4(int V) { return 16 * V + 64 * small_pad4(V); }
+__host__ __device__ inline int small_lds_f4(int V) { return 16 * V + (small_pad_mode(V) ? 64 : 0); }
 
 struct SmallGeom {
   int B, maxT, maxU1, V, blank;
@@ -102,7 +107,7 @@ __device__ __forceinline__ void small_write_record(const Ws& w, const SmallGeom&
   if (t == g.maxT - 1) (frame0 + (size_t)g.maxT * g.maxU1)[u] = neg;
 }
 
-template <int VEC, bool PAD>
+template <int VEC, int PAD, int NLD>
 __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restrict__ x,
                                                            const int32_t* __restrict__ labels,
                                                            const int32_t* __restrict__ in_len,
@@ -113,8 +118,13 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
   const int tile_f4 = 16 * V;  // 64 rows * V floats / 4
   float4* tile4 = lds4 + wv * (tile_f4 + (PAD ? 64 : 0));
   const float* rowp = reinterpret_cast<const float*>(tile4) + lane * (V + (PAD ? 4 : 0));
-  // float4 number q of the tile in memory order -> its LDS slot; PAD (V = 64, 16 float4 per row): q + row of q
-  auto slot = [&](int q) { return PAD ? q + (q >> 4) : q; };
+  // float4 number q of the tile in memory order -> its LDS slot: q + (row of q) when rows are padded.  PAD = 1:
+  // 16 float4 per row; PAD = 2: row = q / (V/4) as a multiply by the rounded-up reciprocal (exact for q < 2048,
+  // V/4 <= 32)
+  const unsigned recip = PAD == 2 ? (65536u + (unsigned)(V / 4) - 1u) / (unsigned)(V / 4) : 0u;
+  auto slot = [&](int q) {
+    return PAD == 1 ? q + (q >> 4) : PAD == 2 ? q + (int)(__umul24((unsigned)q, recip) >> 16) : q;
+  };
   const int gw = blockIdx.x * kSmallWaves + wv, nw = gridDim.x * kSmallWaves;
   const f4v* x4 = reinterpret_cast<const f4v*>(x);
 
@@ -124,12 +134,12 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
     return in_range & (t < T) & (u <= U);
   };
 
-  f4v st[kSmallNld];
+  f4v st[NLD];
   auto issue = [&](int n, bool any) {
     if (!any) return;
     const f4v* src = x4 + (size_t)n * tile_f4;
 #pragma unroll
-    for (int i = 0; i < kSmallNld; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int q = lane + 64 * i;
       if (q < tile_f4) st[i] = __builtin_nontemporal_load(src + q);
     }
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
     // stage the tile into LDS (only this wavefront touches it: in-order LDS, no barrier needed)
     if (any) {
 #pragma unroll
-      for (int i = 0; i < kSmallNld; ++i) {
+      for (int i = 0; i < NLD; ++i) {
         const int q = lane + 64 * i;
         if (q < tile_f4) tile4[slot(q)] = make_float4(st[i].x, st[i].y, st[i].z, st[i].w);
       }
@@ -283,7 +293,7 @@ __device__ __forceinline__ float small_row_grad(const float* src, float* dst, in
   return sq;
 }
 
-template <int VEC, bool PAD>
+template <int VEC, int PAD, int NLD>
 __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, float* grad,
                                                             const int32_t* __restrict__ labels,
                                                             const int32_t* __restrict__ in_len,
@@ -295,7 +305,10 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
   const int tile_f4 = 16 * V;
   float4* tile4 = lds4 + wv * (tile_f4 + (PAD ? 64 : 0));
   float* rowp = reinterpret_cast<float*>(tile4) + lane * (V + (PAD ? 4 : 0));
-  auto slot = [&](int q) { return PAD ? q + (q >> 4) : q; };  // see k_lse_small
+  const unsigned recip = PAD == 2 ? (65536u + (unsigned)(V / 4) - 1u) / (unsigned)(V / 4) : 0u;
+  auto slot = [&](int q) {  // see k_lse_small
+    return PAD == 1 ? q + (q >> 4) : PAD == 2 ? q + (int)(__umul24((unsigned)q, recip) >> 16) : q;
+  };
   const int gw = blockIdx.x * kSmallWaves + wv, nw = gridDim.x * kSmallWaves;
   const f4v* x4 = reinterpret_cast<const f4v*>(x);
   f4v* g4 = reinterpret_cast<f4v*>(grad);
@@ -319,11 +332,11 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
     return cell_load(w, labels, cb, t, u, cT, cU, g.maxT, g.maxU1, V, in_range);
   };
 
-  f4v st[kSmallNld];
+  f4v st[NLD];
   auto issue = [&](int n, unsigned long long active) {
     const f4v* src = x4 + (size_t)n * tile_f4;
 #pragma unroll
-    for (int i = 0; i < kSmallNld; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int q = lane + 64 * i;
       if (chunk_needed(active, i) && q < tile_f4) st[i] = __builtin_nontemporal_load(src + q);
     }
@@ -350,7 +363,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
   for (; k < g.ntiles_full; k += nw) {
     const int n = last - k;
 #pragma unroll
-    for (int i = 0; i < kSmallNld; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int q = lane + 64 * i;
       if (chunk_needed(active, i) && q < tile_f4) tile4[slot(q)] = make_float4(st[i].x, st[i].y, st[i].z, st[i].w);
     }
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
     // the whole tile (gradients and zero rows) leaves as coalesced 1 KiB stores
     f4v* dst = g4 + (size_t)n * tile_f4;
 #pragma unroll
-    for (int i = 0; i < kSmallNld; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int q = lane + 64 * i;
       if (q < tile_f4) {
         const float4 o = tile4[slot(q)];

@@ -1,12 +1,12 @@
 #!/bin/bash
-# bandwidth of k_lse_small / k_grad_small against the row length: rocprofv3 kernel trace of tools/small_v_probe.py
+# bandwidth of the two streaming passes (k_lse*, k_grad*) against the row length: rocprofv3 kernel trace of tools/small_v_probe.py
 # usage: small_v_stats.sh <out dir name> [V ...]
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$out -- python $GRAFT_REPO_ROOT/tools/small_v_probe.py "$@" > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT && python - "$out" "$@" <<'PY'
 import csv, glob, os, sys
 f = sorted(glob.glob(f'gpurun_out/{sys.argv[1]}/*/*kernel_trace.csv'), key=os.path.getmtime)[-1]
-rows = [r for r in csv.DictReader(open(f)) if 'small' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(f)) if 'k_lse' in r['Kernel_Name'] or 'k_grad' in r['Kernel_Name']]
 Vs = [int(a) for a in sys.argv[2:]] or [32, 40, 62, 64]
 for gi, V in enumerate(Vs):
     for r in rows[gi * 10:(gi + 1) * 10][-2:]:   # five iterations per V: the last lse / grad pair
