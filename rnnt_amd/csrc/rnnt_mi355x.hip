@@ -66,6 +66,14 @@ RowCfg pick_row_cfg(int B, int maxT, int maxU1, int V, int blank, const void* p0
   // accesses; partial-line non-temporal stores are slow), between 8 and 64 lanes
   c.L = 8;
   while (c.L < 64 && c.L < nchunk) c.L <<= 1;
+  // Rows of 17..64 chunks: 16 lanes per row with 2 or 4 chunks each instead of 32 / 64 lanes with one; rows of
+  // 65..128 chunks: 32 lanes with 4 each instead of 64 with 2.  The per-row cost (two reductions over the group,
+  // the record, the cursor) is then paid once per 2-4 loads, the reductions stay inside one or two DPP rows and
+  // a wavefront works on several rows at a time.  Measured at B=64, T=500, U=100 (first / second pass, TB/s):
+  // V=160 2.3 / 1.8 -> 4.7 / 7.0; V=256 3.5 / 2.7 -> 5.0 / 7.0; V=384 4.6 / 5.5 -> 5.4 / 7.2; V=512 5.1 / 6.1 ->
+  // 5.5 / 7.1.
+  if (nchunk > 16 && nchunk <= 64) c.L = 16;
+  else if (nchunk > 64 && nchunk <= 128) c.L = 32;
   const int cpl = (nchunk + c.L - 1) / c.L;  // chunks per lane per row
   c.nc = cpl >= 3 ? 4 : cpl;
   c.g = 4 / c.nc;
@@ -95,7 +103,11 @@ RowCfg pick_row_cfg(int B, int maxT, int maxU1, int V, int blank, const void* p0
     if ((cfg).L == 64 && (cfg).nc == 4) KERNEL<VEC, 64, 4, 1><<<grid_, blk_, LDS, st>>>(__VA_ARGS__);      \
     else if ((cfg).L == 64 && (cfg).nc == 2) KERNEL<VEC, 64, 2, 2><<<grid_, blk_, LDS, st>>>(__VA_ARGS__); \
     else if ((cfg).L == 64) KERNEL<VEC, 64, 1, 4><<<grid_, blk_, LDS, st>>>(__VA_ARGS__);                  \
+    else if ((cfg).L == 32 && (cfg).nc == 4) KERNEL<VEC, 32, 4, 1><<<grid_, blk_, LDS, st>>>(__VA_ARGS__); \
+    else if ((cfg).L == 32 && (cfg).nc == 2) KERNEL<VEC, 32, 2, 2><<<grid_, blk_, LDS, st>>>(__VA_ARGS__); \
     else if ((cfg).L == 32) KERNEL<VEC, 32, 1, 4><<<grid_, blk_, LDS, st>>>(__VA_ARGS__);                  \
+    else if ((cfg).L == 16 && (cfg).nc == 4) KERNEL<VEC, 16, 4, 1><<<grid_, blk_, LDS, st>>>(__VA_ARGS__); \
+    else if ((cfg).L == 16 && (cfg).nc == 2) KERNEL<VEC, 16, 2, 2><<<grid_, blk_, LDS, st>>>(__VA_ARGS__); \
     else if ((cfg).L == 16) KERNEL<VEC, 16, 1, 4><<<grid_, blk_, LDS, st>>>(__VA_ARGS__);                  \
     else KERNEL<VEC, 8, 1, 4><<<grid_, blk_, LDS, st>>>(__VA_ARGS__);                                      \
   } while (0)
