@@ -177,7 +177,7 @@ SmallGeom small_geom(const Call& c, int* blocks) {
   long long want = (g.ntiles_full + kSmallWaves - 1) / kSmallWaves;
   // persistent grid, exactly one resident round: tiles are dealt round-robin to the waves.  Residency per CU is
   // limited by LDS (160 KiB / tile bytes per block) and by registers (6 blocks of two waves).
-  const long long lds_bytes = 16LL * small_lds_f4(c.V) * kSmallWaves;
+  const long long lds_bytes = 16LL * small_lds_f4(c.V, true) * kSmallWaves;  // the larger of the two passes' tiles
   long long per_cu = (160LL * 1024) / lds_bytes;
   if (per_cu > 6) per_cu = 6;
   if (per_cu < 1) per_cu = 1;
@@ -204,9 +204,9 @@ SmallGeom small_geom(const Call& c, int* blocks) {
     }                                                                                                           \
     KERNEL<VEC, PAD, NLD><<<blocks, kSmallBlock, lds, st>>>(__VA_ARGS__);                                       \
   } while (0)
-#define RNNT_SMALL_DISPATCH(KERNEL, V, blocks, lds, st, ...)                                                    \
+#define RNNT_SMALL_DISPATCH(KERNEL, V, GRAD, blocks, lds, st, ...)                                              \
   do {                                                                                                          \
-    const int pm = small_pad_mode(V);                                                                           \
+    const int pm = small_pad_mode(V, GRAD);                                                                     \
     if ((V) <= 64) {                                                                                            \
       if (pm == 1) RNNT_SMALL_LAUNCH(KERNEL, 4, 1, 16, blocks, lds, st, __VA_ARGS__);                           \
       else if ((V) % 4 == 0) RNNT_SMALL_LAUNCH(KERNEL, 4, 0, 16, blocks, lds, st, __VA_ARGS__);                 \
@@ -224,9 +224,9 @@ void launch_lse(const Call& c, int b0, int nb, hipStream_t st) {
   if (b0 == 0 && nb == c.B && use_small(c, c.logits)) {
     int blocks;
     const SmallGeom g = small_geom(c, &blocks);
-    const size_t lds = sizeof(float4) * (size_t)small_lds_f4(c.V) * kSmallWaves;
+    const size_t lds = sizeof(float4) * (size_t)small_lds_f4(c.V, false) * kSmallWaves;
     const float* x0 = c.logits - (size_t)c.t_off * c.maxU1 * c.V;  // frame 0 of the uncropped tensor
-    RNNT_SMALL_DISPATCH(k_lse_small, c.V, blocks, lds, st, x0, c.labels, c.in_len, c.lab_len, g, c.w);
+    RNNT_SMALL_DISPATCH(k_lse_small, c.V, false, blocks, lds, st, x0, c.labels, c.in_len, c.lab_len, g, c.w);
     return;
   }
   const RowCfg cfg = sub_cfg(c, c.logits, b0, nb);
@@ -249,11 +249,11 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
   if (b0 == 0 && nb == c.B && use_small(c, c.grad)) {
     int blocks;
     const SmallGeom g = small_geom(c, &blocks);
-    const size_t lds = sizeof(float4) * (size_t)small_lds_f4(c.V) * kSmallWaves;
+    const size_t lds = sizeof(float4) * (size_t)small_lds_f4(c.V, true) * kSmallWaves;
     const size_t skip = (size_t)c.t_off * c.maxU1 * c.V;  // the cropped frames are rows without a cell: zero-filled
     const float* x0 = c.logits - skip;
     float* g0 = c.grad - skip;
-    RNNT_SMALL_DISPATCH(k_grad_small, c.V, blocks, lds, st, x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
+    RNNT_SMALL_DISPATCH(k_grad_small, c.V, true, blocks, lds, st, x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
     return;
   }
   if (c.t_off > 0 && b0 == 0) {  // gradient of the cropped frames

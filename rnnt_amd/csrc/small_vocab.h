@@ -33,12 +33,19 @@ __host__ __device__ inline int small_nld(int V) { return V <= 64 ? 16 : 32; }
 // up to 64 measured slower in the gradient pass: the address arithmetic costs 14 registers and with them a resident
 // wavefront per SIMD, more than their two-way conflicts do.  Above 64 residency is set by LDS alone (a tile is
 // 17-34 KiB), registers are free: PAD = 2 pads every row of an even number of float4 (general row length).
-__host__ __device__ inline int small_pad_mode(int V) {
+// The two passes keep their own tile layout.  Measured at V = 72 / 80 / 96 / 112 (TB/s, padded against not): first
+// pass 4.1 / 3.6 / 3.8 / 4.7 against 4.8 / 5.0 / 4.9 / 4.6, second pass 5.6 / 5.4 / 5.7 / 5.1 against
+// 5.6 / 4.1 / 5.4 / 5.0 -- so between 64 and 128 only the second pass pads.
+__host__ __device__ inline int small_pad_mode(int V, bool grad_pass) {
   if (V % 4 != 0 || (V / 4) % 2 != 0) return 0;
-  return V == 64 ? 1 : V > 64 ? 2 : 0;
+  if (V == 64) return 1;
+  if (V == 128) return 2;
+  return (V > 64 && grad_pass) ? 2 : 0;
 }
 // float4 slots of a wave's LDS tile
-__host__ __device__ inline int small_lds_f4(int V) { return 16 * V + (small_pad_mode(V) ? 64 : 0); }
+__host__ __device__ inline int small_lds_f4(int V, bool grad_pass) {
+  return 16 * V + (small_pad_mode(V, grad_pass) ? 64 : 0);
+}
 
 struct SmallGeom {
   int B, maxT, maxU1, V, blank;
