@@ -15,6 +15,9 @@ from . import _lib
 from .loss import _ptr, _stream_ptr
 
 
+_UNUSED_FLAG = {}  # per device: the flag word handed to the kernel when it cannot be set (indices checked on the host)
+
+
 def joint_log_softmax(enc, pred=None, enc_index=None, pred_index=None):
     """log_softmax(enc[enc_index[n]] + pred[pred_index[n]]) over the last axis.
 
@@ -28,6 +31,8 @@ def joint_log_softmax(enc, pred=None, enc_index=None, pred_index=None):
     dev = enc.device
     enc = enc.float().contiguous()
     pred = None if pred is None else pred.to(dev).float().contiguous()
+    enc_index = None if enc_index is None else torch.as_tensor(enc_index)
+    pred_index = None if pred_index is None else torch.as_tensor(pred_index)
     fi = None if enc_index is None else enc_index.to(dev, torch.int32).contiguous()
     gi = None if pred_index is None else pred_index.to(dev, torch.int32).contiguous()
     if fi is not None and gi is not None and fi.numel() != gi.numel():
@@ -46,12 +51,28 @@ def joint_log_softmax(enc, pred=None, enc_index=None, pred_index=None):
     out = torch.empty((n, V), dtype=torch.float32, device=dev)
     if n == 0:
         return out
-    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    # Row indices given as host tensors are checked here; without index tensors there is nothing to check.  Only
+    # indices that already live on the device are checked by the kernel, and only then is its flag read back (a
+    # stream sync, ~30 us): the decoders call this once per frame and hypothesis set.
+    on_device = False
+    for idx, rows, what in ((enc_index, enc.shape[0], "enc"), (pred_index, 0 if pred is None else pred.shape[0], "pred")):
+        if idx is None:
+            continue
+        if idx.is_cuda:
+            on_device = True
+        elif idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= rows):
+            raise IndexError(f"joint_log_softmax: a row index lies outside {what}")
+    if on_device:
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    else:
+        bad = _UNUSED_FLAG.get(dev)
+        if bad is None:
+            bad = _UNUSED_FLAG[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.lib().rnnt_mi355x_joint_log_softmax(_ptr(enc), enc.shape[0], _ptr(pred), 0 if pred is None else pred.shape[0],
                                                       _ptr(fi), _ptr(gi), n, V, _ptr(out), _ptr(bad), _stream_ptr(dev))
     _lib.check(rc, "rnnt_mi355x_joint_log_softmax")
-    if int(bad.item()):
+    if on_device and int(bad.item()):
         raise IndexError("joint_log_softmax: a row index lies outside its tensor")
     return out
 

@@ -51,6 +51,10 @@ def test_bad_arguments():
         rnnt_amd.joint_log_softmax(enc, pred, torch.tensor([0, 3]), torch.tensor([0, 1]))
     with pytest.raises(IndexError):
         rnnt_amd.joint_log_softmax(enc, pred, torch.tensor([0, 1]), torch.tensor([0, -1]))
+    with pytest.raises(IndexError):                                # indices already on the device: checked by the kernel
+        rnnt_amd.joint_log_softmax(enc, pred, torch.tensor([0, 3], device=DEV), torch.tensor([0, 1], device=DEV))
+    ok = rnnt_amd.joint_log_softmax(enc, pred, torch.tensor([0, 2], device=DEV), torch.tensor([1, 1], device=DEV))
+    assert ok.shape == (2, 8)
     with pytest.raises(ValueError):
         rnnt_amd.joint_log_softmax(enc, pred)                      # row counts differ, no indices
     with pytest.raises(ValueError):
