@@ -73,6 +73,49 @@ __global__ __launch_bounds__(kBlock) void k_fcj_fwd(const float* __restrict__ pe
   }
 }
 
+// The same, with the work cut by position in memory instead of by (b, t): every block writes kFlatChunk
+// consecutive vectors of h starting on a 32 KiB boundary, whatever U1*H is.  With one block per (b, t) the blocks
+// start wherever their output row starts -- in the middle of a cache line unless U1*H*4 is a multiple of 128 --
+// and every wavefront's store straddles lines (H = 100: 3.9 TB/s against 5.2+ at H = 64, 128).  Needs
+// n = U1*H/VEC >= kFlatChunk, so that a block touches at most two (b, t) rows.
+constexpr int kFlatChunk = 8 * kBlock;
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_fcj_fwd_flat(const float* __restrict__ pe, const float* __restrict__ pd,
+                                                         float* __restrict__ h, long long total, int T, int U1,
+                                                         int H) {
+  const unsigned n = (unsigned)(U1 * H / VEC), hv = (unsigned)(H / VEC);
+  const long long e0 = (long long)blockIdx.x * kFlatChunk;
+  const long long bt0 = e0 / n;                       // uniform
+  const unsigned i0 = (unsigned)(e0 - bt0 * n);
+  const long long b0 = bt0 / T, b1 = (bt0 + 1) / T;   // utterance of the block's first and second (b, t) row
+  unsigned hi = (i0 + threadIdx.x) % hv;              // n is a multiple of hv: moving on to the next row keeps it
+  const unsigned hstep = kBlock % hv;
+#pragma unroll
+  for (int j = 0; j < kFlatChunk / kBlock; ++j) {
+    const unsigned off = threadIdx.x + kBlock * j;
+    const long long e = e0 + off;
+    if (e < total) {
+      unsigned it = i0 + off;
+      const bool next = it >= n;
+      it -= next ? n : 0u;
+      const float* per = pe + (size_t)(bt0 + (next ? 1 : 0)) * H;
+      const float* pdb = pd + (size_t)(next ? b1 : b0) * U1 * H;
+      if constexpr (VEC == 4) {
+        const f4v a = *reinterpret_cast<const f4v*>(per + 4 * hi);
+        const f4v c = *reinterpret_cast<const f4v*>(pdb + 4 * (size_t)it);
+        f4v r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = tanh_fast(a[k] + c[k]);
+        __builtin_nontemporal_store(r, reinterpret_cast<f4v*>(h) + e);
+      } else {
+        __builtin_nontemporal_store(tanh_fast(per[hi] + pdb[it]), h + e);
+      }
+    }
+    hi += hstep;
+    if (hi >= hv) hi -= hv;
+  }
+}
+
 // One block per (b, chunk of kFrames frames).  For every tile of `rows` label positions and every frame of the
 // chunk: d = dh * (1 - tanh^2(pe + pd)) goes to an LDS tile [rows][H]; the threads keep the sums over the
 // chunk's frames of their own tile elements in registers (-> partial[b][chunk][u][h]) and, after a barrier,
@@ -217,8 +260,16 @@ int rnnt_mi355x_fc_joint_forward(const float* pe, const float* pd, int B, int T,
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const bool vec = H % 4 == 0 && (reinterpret_cast<uintptr_t>(pe) | reinterpret_cast<uintptr_t>(pd) |
                                   reinterpret_cast<uintptr_t>(h)) % 16 == 0;
-  if (vec) k_fcj_fwd<4><<<B * T, kBlock, 0, st>>>(pe, pd, h, T, U1, H);
-  else k_fcj_fwd<1><<<B * T, kBlock, 0, st>>>(pe, pd, h, T, U1, H);
+  const long long n = (long long)U1 * H / (vec ? 4 : 1), total = (long long)B * T * n;
+  if (n >= kFlatChunk) {  // blocks aligned in memory
+    const unsigned grid = (unsigned)((total + kFlatChunk - 1) / kFlatChunk);
+    if (vec) k_fcj_fwd_flat<4><<<grid, kBlock, 0, st>>>(pe, pd, h, total, T, U1, H);
+    else k_fcj_fwd_flat<1><<<grid, kBlock, 0, st>>>(pe, pd, h, total, T, U1, H);
+  } else if (vec) {
+    k_fcj_fwd<4><<<B * T, kBlock, 0, st>>>(pe, pd, h, T, U1, H);
+  } else {
+    k_fcj_fwd<1><<<B * T, kBlock, 0, st>>>(pe, pd, h, T, U1, H);
+  }
   return status();
 }
 
