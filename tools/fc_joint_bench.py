@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=32); ap.add_argument("--T", type=int, default=502); ap.add_argument("--U", type=int, default=100)
 ap.add_argument("--He", type=int, default=256); ap.add_argument("--Hd", type=int, default=128); ap.add_argument("--H", type=int, default=100)
 ap.add_argument("--V", type=int, default=62); ap.add_argument("--layers", type=int, default=2); ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--ours-only", action="store_true", help="skip the literal composition (for a kernel profile of the fused head alone)")
 a = ap.parse_args()
 dev = torch.device("cuda:0"); B, T0, U, V = a.B, a.T, a.U, a.V
 yt = torch.randn(B, T0, a.He, device=dev, requires_grad=True); yp = torch.randn(B, U + 1, a.Hd, device=dev, requires_grad=True)
@@ -38,6 +39,9 @@ def timeit(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / a.reps
 ours(); g1 = [p.grad.clone() for p in params]
+if a.ours_only:
+    print(f"ours {timeit(ours):.3f} ms")
+    sys.exit(0)
 literal(); g2 = [p.grad.clone() for p in params]
 print("max grad difference ours vs literal:", max((x - y).abs().max().item() for x, y in zip(g1, g2)))
 t1, t2 = timeit(ours), timeit(literal)
