@@ -126,18 +126,20 @@ template <int NG, int VEC>
 __global__ __launch_bounds__(kBlock) void k_fcj_bwd(const float* __restrict__ pe, const float* __restrict__ pd,
                                                     const float* __restrict__ dh, float* __restrict__ dpe,
                                                     float* __restrict__ partial, int T, int U1, int H, int rows,
-                                                    int nchunk) {
-  extern __shared__ float lds[];  // tile[rows*H], dpe_acc[kFrames*H], pe_s[kFrames*H]
+                                                    int nchunk, int rg) {
+  // tile[rows*H], dpe_acc[kFrames][rg][H] (the rows of a tile are summed in rg groups by different threads; the
+  // groups are added up, in order, at the end), pe_s[kFrames*H]
+  extern __shared__ float lds[];
   float* tile = lds;
   float* dpe_acc = lds + (size_t)rows * H;
-  float* pe_s = dpe_acc + kFrames * H;
+  float* pe_s = dpe_acc + (size_t)kFrames * rg * H;
   const int b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk;
   const int t0 = chunk * kFrames, nt = min(kFrames, T - t0);
-  for (int i = threadIdx.x; i < kFrames * H; i += kBlock) {
-    dpe_acc[i] = 0.f;
+  for (int i = threadIdx.x; i < kFrames * rg * H; i += kBlock) dpe_acc[i] = 0.f;
+  for (int i = threadIdx.x; i < kFrames * H; i += kBlock)
     pe_s[i] = (i < nt * H) ? pe[((size_t)b * T + t0) * H + i] : 0.f;
-  }
   __syncthreads();
+  const int hv = H / VEC;
   const float* pdb = pd + (size_t)b * U1 * H;
   float* part = partial + ((size_t)b * nchunk + chunk) * U1 * H;
   auto ldv = [](const float* p, float (&v)[VEC]) {
@@ -192,16 +194,21 @@ __global__ __launch_bounds__(kBlock) void k_fcj_bwd(const float* __restrict__ pe
         if (i < n) stv(tile + (size_t)i * VEC, d);
       }
       __syncthreads();
-      for (int hc = threadIdx.x * VEC; hc < H; hc += kBlock * VEC) {
+      // column sums of the tile: rg threads per column group, each over its share of the rows (fixed order)
+      const int rper = (nr + rg - 1) / rg;
+      for (int idx = threadIdx.x; idx < rg * hv; idx += kBlock) {
+        const int g = idx / hv, hc = (idx - g * hv) * VEC;
+        float* accp = dpe_acc + ((size_t)tt * rg + g) * H + hc;
         float sum[VEC];
-        ldv(dpe_acc + tt * H + hc, sum);
-        for (int r = 0; r < nr; ++r) {
+        ldv(accp, sum);
+        const int r1 = min(nr, (g + 1) * rper);
+        for (int r = g * rper; r < r1; ++r) {
           float tv[VEC];
           ldv(tile + r * H + hc, tv);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) sum[e] += tv[e];
         }
-        stv(dpe_acc + tt * H + hc, sum);
+        stv(accp, sum);
       }
       __syncthreads();
     }
@@ -211,7 +218,12 @@ __global__ __launch_bounds__(kBlock) void k_fcj_bwd(const float* __restrict__ pe
       if (i < n) stv(part + (size_t)u0 * H + (size_t)i * VEC, acc[k]);
     }
   }
-  for (int i = threadIdx.x; i < nt * H; i += kBlock) dpe[((size_t)b * T + t0) * H + i] = dpe_acc[i];
+  for (int i = threadIdx.x; i < nt * H; i += kBlock) {
+    const int tt = i / H, hc = i - tt * H;
+    float sum = 0.f;
+    for (int g = 0; g < rg; ++g) sum += dpe_acc[((size_t)tt * rg + g) * H + hc];
+    dpe[((size_t)b * T + t0) * H + i] = sum;
+  }
 }
 
 // dpd[b][i] = sum over the frame chunks of partial[b][chunk][i], i in [0, U1*H)
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void k_fcj_bwd_reduce(const float* __restri
   dpd[i] = s;
 }
 
-constexpr int kMaxH = 1536;  // tile + two [kFrames][H] arrays must fit the 160 KiB of LDS
+constexpr int kMaxH = 1536;  // tile + [kFrames][rg][H] + [kFrames][H] must fit the 160 KiB of LDS (rg = 1 when H > 512)
 
 int check_dims(int B, int T, int U1, int H) {
   if (B < 1 || T < 1 || U1 < 1 || H < 1) return RNNT_MI355X_INVALID_VALUE;
@@ -281,10 +293,13 @@ int rnnt_mi355x_fc_joint_backward(const float* pe, const float* pd, const float*
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const int nchunk = (T + kFrames - 1) / kFrames;
   const int rows = tile_rows(U1, H);
-  const size_t lds = sizeof(float) * ((size_t)rows * H + 2 * (size_t)kFrames * H);
-  float* partial = static_cast<float*>(workspace);
   const bool vec = H % 4 == 0 && (reinterpret_cast<uintptr_t>(pd) | reinterpret_cast<uintptr_t>(dh) |
                                   reinterpret_cast<uintptr_t>(workspace)) % 16 == 0;
+  // threads per column group of the tile's column sums: as many as the block has for them, at most 4
+  int rg = kBlock / (H / (vec ? 4 : 1) > 0 ? H / (vec ? 4 : 1) : 1);
+  rg = rg < 1 ? 1 : rg > 4 ? 4 : rg;  // 8 measured slower at H = 100, 128 (LDS for the partial sums costs a resident block)
+  const size_t lds = sizeof(float) * ((size_t)rows * H + (size_t)kFrames * rg * H + (size_t)kFrames * H);
+  float* partial = static_cast<float*>(workspace);
   const int ng = (rows * H / (vec ? 4 : 1) + kBlock - 1) / kBlock;  // groups per thread and tile: <= 8 (vec) or 32
   const dim3 grid((unsigned)(B * nchunk));
 #define FCJ_BWD(N, V)                                                                                       \
@@ -293,7 +308,7 @@ int rnnt_mi355x_fc_joint_backward(const float* pe, const float* pd, const float*
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcj_bwd<N, V>),                                \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)           \
       return RNNT_MI355X_LAUNCH_FAILURE;                                                                    \
-    k_fcj_bwd<N, V><<<grid, kBlock, lds, st>>>(pe, pd, dh, dpe, partial, T, U1, H, rows, nchunk);           \
+    k_fcj_bwd<N, V><<<grid, kBlock, lds, st>>>(pe, pd, dh, dpe, partial, T, U1, H, rows, nchunk, rg);       \
   } while (0)
   if (vec) {
     if (ng <= 2) FCJ_BWD(2, 4);
