@@ -191,17 +191,12 @@ SmallGeom small_geom(const Call& c, int* blocks) {
 }
 
 // Instantiation of a small-vocabulary kernel for V: vector width of the row loops, LDS padding mode, staging depth.
-// Tiles above 64 KiB per block need the dynamic-LDS limit raised (once per instantiation).
+// Tiles above 64 KiB per block need the dynamic-LDS limit raised.
 #define RNNT_SMALL_LAUNCH(KERNEL, VEC, PAD, NLD, blocks, lds, st, ...)                                          \
   do {                                                                                                          \
-    if ((lds) > 48 * 1024) {                                                                                    \
-      static bool raised = false;                                                                               \
-      if (!raised) {                                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<VEC, PAD, NLD>),                        \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                       \
-        raised = true;                                                                                          \
-      }                                                                                                         \
-    }                                                                                                           \
+    if ((lds) > 48 * 1024) /* per device, so not cached in a process-wide flag */                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<VEC, PAD, NLD>),                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                         \
     KERNEL<VEC, PAD, NLD><<<blocks, kSmallBlock, lds, st>>>(__VA_ARGS__);                                       \
   } while (0)
 #define RNNT_SMALL_DISPATCH(KERNEL, V, GRAD, blocks, lds, st, ...)                                              \
