@@ -43,6 +43,8 @@ def _prepare(acts, labels, input_lengths, label_lengths, blank_label):
 
 
 def _prepare_meta(B, T, U1, V, dev, labels, input_lengths, label_lengths, blank_label):
+    if B < 1:
+        raise ValueError("rnnt_loss: empty batch")
     labels_in = torch.as_tensor(labels)
     labels = labels_in.to(device=dev, dtype=torch.int32).reshape(B, -1)
     if labels.shape[1] != U1 - 1:

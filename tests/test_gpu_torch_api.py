@@ -121,6 +121,12 @@ def test_malformed_inputs_raise():
         rnnt_amd.rnnt_loss(acts, lab[:, :2], il, ll, 7)
 
 
+def test_empty_batch_is_rejected_cleanly():
+    acts = torch.zeros(0, 4, 3, 5, device=DEV)
+    with pytest.raises(ValueError, match="empty batch"):
+        rnnt_amd.rnnt_loss(acts, torch.zeros(0, 2, dtype=torch.int32), torch.zeros(0), torch.zeros(0), 0)
+
+
 def test_sharded_run_equals_unsharded():
     """Every rank's shard computed one after the other on the one GPU ("fake
     world"): the all-reduced scalars and the per-utterance results must equal
