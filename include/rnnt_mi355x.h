@@ -107,7 +107,7 @@ int rnnt_mi355x_backward_strided(const float* logits, size_t logits_batch_stride
  * rnnt_mi355x_workspace_bytes(B, T0 - t_offset, maxU1)).  The backward writes
  * zeros into the t_offset skipped frames of grad_full (which may be
  * logits_full itself).  Unlike the *_strided forms this tells the library
- * that the tensor is dense, which the small-vocabulary kernels (V <= 64: the
+ * that the tensor is dense, which the small-vocabulary kernels (V <= 128: the
  * reference's own 40/62-symbol vocabularies) need. */
 int rnnt_mi355x_forward_cropped(const float* logits_full, const int32_t* labels, const int32_t* in_len,
                                 const int32_t* lab_len, int B, int T0, int t_offset, int maxU1, int V, int blank,

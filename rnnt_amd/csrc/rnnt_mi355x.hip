@@ -28,7 +28,7 @@
 //   workspace.h      constants, workspace header and layout
 //   device_util.h    exp2/log2, vector loads, DPP reductions, row cursor
 //   lse_rows.h       k_lse                 grad_rows.h   k_grad
-//   sweep.h          k_sweep               small_vocab.h V <= 64 variants of both passes
+//   sweep.h          k_sweep               small_vocab.h V <= 128 variants of both passes
 //   joint.h          additive joint fused into the loss (matrix-core contractions)
 //   aux_kernels.h    zero-fill of cropped frames, workspace init, batch scalars
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-// Part of the single translation unit rnnt_mi355x.hip: the small-vocabulary (V <= 64) variants of the two streaming passes.
+// Part of the single translation unit rnnt_mi355x.hip: the small-vocabulary (V <= 128) variants of the two streaming passes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -10,8 +10,8 @@
 namespace {
 
 // ---------------------------------------------------------------------------
-// Small-vocabulary variants (V <= 64: the phone-level vocabularies the
-// reference trains on, V = 40 / 62).  A row is only V*4 <= 256 bytes, so
+// Small-vocabulary variants (V <= 128: the phone-level vocabularies the
+// reference trains on, V = 40 / 62, and character sets).  A row is only V*4 <= 512 bytes, so
 // splitting it over lanes spends more on cross-lane reductions than on the
 // row itself.  Instead a wavefront streams tiles of 64 consecutive rows
 // (16*V float4, coalesced) through registers into LDS and then every LANE
