@@ -30,6 +30,7 @@ constexpr int kTileFloats = 8192;   // LDS tile of the backward pass: label posi
 constexpr float kTwoLog2e = 2.885390081777927f;
 
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 
 // tanh(x) = 1 - 2 / (2^(2x log2 e) + 1); exact limits at +-inf, relative error ~2e-7
 __device__ __forceinline__ float tanh_fast(float x) {
@@ -107,6 +108,11 @@ __global__ __launch_bounds__(kBlock) void k_fcj_fwd_flat(const float* __restrict
 #pragma unroll
         for (int k = 0; k < 4; ++k) r[k] = tanh_fast(a[k] + c[k]);
         __builtin_nontemporal_store(r, reinterpret_cast<f4v*>(h) + e);
+      } else if constexpr (VEC == 2) {
+        const f2v a = *reinterpret_cast<const f2v*>(per + 2 * hi);
+        const f2v c = *reinterpret_cast<const f2v*>(pdb + 2 * (size_t)it);
+        const f2v r = {tanh_fast(a[0] + c[0]), tanh_fast(a[1] + c[1])};
+        __builtin_nontemporal_store(r, reinterpret_cast<f2v*>(h) + e);
       } else {
         __builtin_nontemporal_store(tanh_fast(per[hi] + pdb[it]), h + e);
       }
@@ -272,10 +278,14 @@ int rnnt_mi355x_fc_joint_forward(const float* pe, const float* pd, int B, int T,
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const bool vec = H % 4 == 0 && (reinterpret_cast<uintptr_t>(pe) | reinterpret_cast<uintptr_t>(pd) |
                                   reinterpret_cast<uintptr_t>(h)) % 16 == 0;
-  const long long n = (long long)U1 * H / (vec ? 4 : 1), total = (long long)B * T * n;
+  const bool vec2 = !vec && H % 2 == 0 && (reinterpret_cast<uintptr_t>(pe) | reinterpret_cast<uintptr_t>(pd) |
+                                           reinterpret_cast<uintptr_t>(h)) % 8 == 0;
+  const int vw = vec ? 4 : vec2 ? 2 : 1;
+  const long long n = (long long)U1 * H / vw, total = (long long)B * T * n;
   if (n >= kFlatChunk) {  // blocks aligned in memory
     const unsigned grid = (unsigned)((total + kFlatChunk - 1) / kFlatChunk);
-    if (vec) k_fcj_fwd_flat<4><<<grid, kBlock, 0, st>>>(pe, pd, h, total, T, U1, H);
+    if (vw == 4) k_fcj_fwd_flat<4><<<grid, kBlock, 0, st>>>(pe, pd, h, total, T, U1, H);
+    else if (vw == 2) k_fcj_fwd_flat<2><<<grid, kBlock, 0, st>>>(pe, pd, h, total, T, U1, H);
     else k_fcj_fwd_flat<1><<<grid, kBlock, 0, st>>>(pe, pd, h, total, T, U1, H);
   } else if (vec) {
     k_fcj_fwd<4><<<B * T, kBlock, 0, st>>>(pe, pd, h, T, U1, H);

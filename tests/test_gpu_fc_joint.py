@@ -23,7 +23,8 @@ def _p(t):
 
 # B, T, U1, H: vector and scalar paths, several LDS tiles per utterance (U1*H > 8192), ragged frame chunks,
 # an H that needs more than the default dynamic LDS
-FIRST_LAYER_SHAPES = [(2, 9, 5, 100), (1, 8, 3, 7), (2, 17, 40, 256), (1, 5, 101, 100), (1, 3, 4, 1024), (2, 1, 1, 1)]
+FIRST_LAYER_SHAPES = [(2, 9, 5, 100), (1, 8, 3, 7), (2, 17, 40, 256), (1, 5, 101, 100), (1, 3, 4, 1024), (2, 1, 1, 1),
+                      (2, 3, 70, 62), (1, 2, 300, 7)]  # the forward cut by position in memory: 8-byte and scalar paths
 
 
 @pytest.mark.parametrize("B,T,U1,H", FIRST_LAYER_SHAPES)
