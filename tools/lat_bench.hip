@@ -11,7 +11,12 @@ template <int OP>
 __device__ __forceinline__ void op(double& x, float& f, int& lo, double seed, float fseed) {
   if (OP == 0) x = x + seed;                                                     // v_add_f64
   if (OP == 1) x = fmax(x, seed) ;                                               // v_max_f64
-  if (OP == 2) { f = (float)x; x = (double)f; }                                  // v_cvt_f32_f64 + v_cvt_f64_f32
+  if (OP == 2) {                                                                 // v_cvt_f32_f64 + v_cvt_f64_f32
+    asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f) : "v"(x));
+    asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(x) : "v"(f));
+  }
+  if (OP == 7) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(x) : "v"(f));         // v_cvt_f64_f32 alone (f never changes)
+  if (OP == 8) asm volatile("v_max_f64 %0, %1, %2" : "=v"(x) : "v"(x), "v"(seed));
   if (OP == 3) f = __builtin_amdgcn_exp2f(-f);                                   // v_exp_f32
   if (OP == 4) f = __builtin_amdgcn_logf(f);                                     // v_log_f32
   if (OP == 5) f = f + fseed;                                                    // v_add_f32
@@ -31,10 +36,6 @@ __global__ __launch_bounds__(64) void k_chain(double* out, double seed, float fs
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int c = 0; c < NCH; ++c) op<OP>(x[c], f[c], lo[c], seed, fseed);
-    if (OP == 2) {  // keep the conversions from being folded away
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(x[c]));
-    }
   }
   double s = 0;
 #pragma unroll
@@ -60,6 +61,8 @@ int main() {
   printf("%-28s dep %6.2f ns   ind %6.2f ns\n", "v_add_f64", run<0, 1>(d), run<0, 8>(d));
   printf("%-28s dep %6.2f ns   ind %6.2f ns\n", "v_max_f64", run<1, 1>(d), run<1, 8>(d));
   printf("%-28s dep %6.2f ns   ind %6.2f ns  (two operations)\n", "cvt f64->f32->f64", run<2, 1>(d), run<2, 8>(d));
+  printf("%-28s                 ind %6.2f ns\n", "v_cvt_f64_f32", run<7, 8>(d));
+  printf("%-28s dep %6.2f ns   ind %6.2f ns\n", "v_max_f64 (asm)", run<8, 1>(d), run<8, 8>(d));
   printf("%-28s dep %6.2f ns   ind %6.2f ns\n", "v_exp_f32", run<3, 1>(d), run<3, 8>(d));
   printf("%-28s dep %6.2f ns   ind %6.2f ns\n", "v_log_f32", run<4, 1>(d), run<4, 8>(d));
   printf("%-28s dep %6.2f ns   ind %6.2f ns\n", "v_add_f32", run<5, 1>(d), run<5, 8>(d));
