@@ -26,7 +26,14 @@ namespace {
 // ldexp, add, frexp instead of exp2/log2 on the chain -- gave the same results
 // and was also slower (one column per lane 77 us against 61 us, two columns
 // 135 us against 76 us at T=500): the float64 ldexp/frexp steps cost more than
-// the transcendentals they replace.  Measured per diagonal: 109 ns with one
+// the transcendentals they replace.  A second multi-wavefront form without a barrier on the chain -- one column per
+// lane, wavefront w owning columns 64w..64w+63, the one number per diagonal a wavefront needs from its neighbour left
+// in an LDS array indexed by the diagonal, progress counters looked at every 64 diagonals so that a wavefront just
+// trails its neighbour -- was correct and gave 117 us against 158 us at U+1 = 200 and 235 us against 440 us at
+// U+1 = 400 (T=500, B=32), but 59 us against 55 us at U+1 = 101 and nothing at B=128: every wavefront's load of a
+// diagonal touches 64 cache lines and the compute unit's vector cache takes them one per cycle whichever wavefront
+// asks, so W wavefronts cost ~35 ns x W per diagonal.  Not kept: its gain is confined to long label sequences in
+// small batches.  Measured per diagonal: 109 ns with one
 // column per lane, 127 ns with two, 230 ns with four, 494 ns with eight.  Cutting the loop from 30 to 24
 // instructions per diagonal (constant row stride, leaner address arithmetic, shifts that keep the boundary lane's
 // "log 0") brought 105 / 122 / 225 / 488 ns: the dependent chain, not instruction issue, sets the pace.
