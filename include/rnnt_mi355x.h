@@ -28,9 +28,11 @@
  *     contains the log-softmax backward; cells with t >= in_len[b] or
  *     u > lab_len[b] receive exact zeros;
  *   - the caller owns every buffer including the workspace; no entry point
- *     allocates or frees device memory, none keeps global state, all work is
- *     enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and,
- *     except rnnt_mi355x_read_status, none synchronises;
+ *     allocates or frees device memory, all work is enqueued on `hip_stream`
+ *     (a hipStream_t, NULL = default stream; its device must be the current
+ *     one) and, except rnnt_mi355x_read_status / rnnt_mi355x_read_stats, none
+ *     synchronises; the only state the library keeps between calls is the
+ *     pruning threshold of rnnt_mi355x_set_prune_log2;
  *   - every function returns an rnnt_mi355x_status; nothing throws or aborts.
  *
  * Limits: 1 <= maxU1 <= 1024, B*maxT*maxU1 < 2^31, (maxT+2)*maxU1 < 2^28,
@@ -123,14 +125,16 @@ int rnnt_mi355x_loss_grad(float* logits_inout, const int32_t* labels, const int3
                           int B, int maxT, int maxU1, int V, int blank, const float* grad_scale, float* costs,
                           void* workspace, void* hip_stream);
 
-/* rnnt_mi355x_loss_grad with two optional hipEvent_t handles recorded on
- * `hip_stream` immediately before and after the gradient-kernel launch (NULL = not recorded).  A measurement aid for callers that want the
- * gradient pass timed on the launch stream; it has no counterpart in the
- * reference. */
+/* rnnt_mi355x_loss_grad with optional hipEvent_t handles recorded on
+ * `hip_stream` around its kernels: events4[0] before the log-sum-exp pass,
+ * [1] between it and the lattice sweep, [2] between the sweep and the gradient
+ * pass, [3] after the gradient pass (events4 NULL, or any entry NULL = not
+ * recorded).  A measurement aid for callers that want each pass timed on the
+ * launch stream; it has no counterpart in the reference. */
 int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, const int32_t* in_len,
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
                                  const float* grad_scale, float* costs, void* workspace, void* hip_stream,
-                                 void* ev_grad_begin, void* ev_grad_end);
+                                 void* const* events4);
 
 /* ---- fused additive joint ------------------------------------------------
  * The loss of the reference's additive-joint model, Util.rnnt_lambda_func
@@ -210,6 +214,23 @@ int rnnt_mi355x_joint_log_softmax(const float* f, int f_rows, const float* g, in
  * reference keras_model.py:215-217 and the gradient norm the optimizer's
  * clipnorm needs (reference keras_model.py:209-213). */
 int rnnt_mi355x_reduce_scalars(const float* costs, int B, void* workspace, double* out2, void* hip_stream);
+
+/* The gradient kernels skip lattice cells whose occupancy
+ * gamma = P(path through (t,u) | labels) is below 2^log2_threshold: every
+ * element of such a row's gradient is bounded by grad_scale*gamma, so the row
+ * is written as exact zeros and its logits are not read a second time.
+ * Default -40 (9e-13); accepted range [-inf, -16] (-inf: nothing is pruned).
+ * Process-wide; takes effect for backward calls enqueued afterwards.  A
+ * tuning knob without counterpart in the reference (whose dependency computes
+ * every element). */
+int rnnt_mi355x_set_prune_log2(float log2_threshold);
+float rnnt_mi355x_get_prune_log2(void);
+
+/* *host_cells = lattice cells the last backward on this workspace visited,
+ * *host_pruned = how many of them fell below the pruning threshold.  Runs a
+ * small kernel and waits for the stream.  A measurement aid without
+ * counterpart in the reference. */
+int rnnt_mi355x_read_stats(void* workspace, uint64_t* host_cells, uint64_t* host_pruned, void* hip_stream);
 
 /* Copies the device-side validation word to *host_flags (an OR of
  * RNNT_MI355X_FLAG_*), waiting for the stream.  Returns

@@ -36,7 +36,10 @@ _SIGNATURES = {
     "rnnt_mi355x_backward_cropped": (ctypes.c_int, [_vp] * 5 + [_i] * 6 + [_vp, _vp, _vp]),
     "rnnt_mi355x_backward_inplace": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp]),
     "rnnt_mi355x_loss_grad": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp]),
-    "rnnt_mi355x_loss_grad_events": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "rnnt_mi355x_loss_grad_events": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
+    "rnnt_mi355x_set_prune_log2": (ctypes.c_int, [ctypes.c_float]),
+    "rnnt_mi355x_get_prune_log2": (ctypes.c_float, []),
+    "rnnt_mi355x_read_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), _vp]),
     "rnnt_mi355x_joint_workspace_bytes": (ctypes.c_int, [_i, _i, _i, _i, ctypes.POINTER(_sz)]),
     "rnnt_mi355x_joint_forward": (ctypes.c_int, [_vp, _sz] + [_vp] * 4 + _META + [_vp, _vp, _vp]),
     "rnnt_mi355x_joint_backward": (ctypes.c_int, [_vp, _sz] + [_vp] * 4 + _META + [_vp, _vp, _sz, _vp, _vp, _vp]),
@@ -107,6 +110,14 @@ def joint_workspace_bytes(B: int, maxT: int, maxU1: int, V: int) -> int:
     out = _sz(0)
     check(lib().rnnt_mi355x_joint_workspace_bytes(B, maxT, maxU1, V, ctypes.byref(out)), "rnnt_mi355x_joint_workspace_bytes")
     return int(out.value)
+
+
+def read_stats(workspace_ptr, stream_ptr):
+    """(lattice cells, pruned cells) of the last backward on that workspace."""
+    cells, pruned = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(lib().rnnt_mi355x_read_stats(workspace_ptr, ctypes.byref(cells), ctypes.byref(pruned), stream_ptr),
+          "rnnt_mi355x_read_stats")
+    return int(cells.value), int(pruned.value)
 
 
 def workspace_bytes(B: int, maxT: int, maxU1: int) -> int:

@@ -23,6 +23,37 @@ __global__ __launch_bounds__(64) void k_init(Ws w, int n_partial) {
     w.hdr->n_fallback = 0;
     w.hdr->n_partial = n_partial;
     w.hdr->partial_off = w.partial_off;
+    w.hdr->count_off = w.count_off;
+    w.hdr->n_cells = 0;
+    w.hdr->n_pruned = 0;
+  }
+}
+
+// Sums the per-block {cells, pruned cells} counts of the last gradient pass into the header (fixed order).
+__global__ __launch_bounds__(1024) void k_reduce_counts(char* ws_base) {
+  __shared__ unsigned long long sh[2][1024];
+  Header* hdr = reinterpret_cast<Header*>(ws_base);
+  const uint2* pc = reinterpret_cast<const uint2*>(ws_base + hdr->count_off);
+  const int n = hdr->n_partial;
+  unsigned long long c = 0, p = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const uint2 v = pc[i];
+    c += v.x;
+    p += v.y;
+  }
+  sh[0][threadIdx.x] = c;
+  sh[1][threadIdx.x] = p;
+  __syncthreads();
+  for (int o = 512; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    hdr->n_cells = sh[0][0];
+    hdr->n_pruned = sh[1][0];
   }
 }
 

@@ -55,7 +55,9 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(8))) 
   utt_dims(in_len, lab_len, b, gm.maxT, maxU1, T, U);
 
   extern __shared__ float4 coef_s[];  // one entry per row of the block
+  __shared__ int cnt_s[2][kRowWaves];
   {
+    int n_cell = 0, n_pruned = 0;  // wave-uniform (ballot counts)
     const int U1s = w.U1s;
     const size_t plane = (size_t)b * w.D * U1s;
     const double ll2 = w.ll[b];
@@ -64,12 +66,13 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(8))) 
       const int u = i - tt * maxU1;
       const int t = t0 + tt;
       float4 cf = make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
-      if (t < T && u <= U) {
+      const bool is_cell = t < T && u <= U;
+      if (is_cell) {
         const size_t ci = plane + (size_t)(t + u) * U1s + u;
         const double a_ll = w.alpha[ci] - ll2;
         const float4 rc = w.rec[((size_t)b * (gm.maxT + 2) + 1 + t) * maxU1 + u];  // {lpb, lpl, lse, -}
         const float g2 = (float)(a_ll + w.beta[ci]);   // log2 gamma
-        if (g2 >= kPruneLog2) {
+        if (g2 >= gm.prune_log2) {
           float e_b = -INFINITY;  // 2^-inf = 0: no blank move out of this cell
           if (t < T - 1) e_b = (float)(a_ll + w.beta[ci + U1s]) + rc.x;
           else if (u == U) e_b = (float)a_ll + rc.x;
@@ -84,10 +87,19 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(8))) 
         }
       }
       coef_s[i] = cf;
+      n_cell += __popcll(__ballot(is_cell));
+      n_pruned += __popcll(__ballot(is_cell && !(cf.x > -INFINITY)));
     }
+    if (lane == 0) { cnt_s[0][wv] = n_cell; cnt_s[1][wv] = n_pruned; }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) w.hdr->n_partial = gm.nblocks_all;
   __syncthreads();
+  if (threadIdx.x == 0) {
+    uint2 c = make_uint2(0u, 0u);
+#pragma unroll
+    for (int i = 0; i < kRowWaves; ++i) { c.x += cnt_s[0][i]; c.y += cnt_s[1][i]; }
+    w.pcount[gm.b0 * gm.nTB + bid] = c;
+  }
 
   RowCursor<G> cur;
   cur.init(wv * G * R + r, R, maxU1);

@@ -80,6 +80,9 @@ __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f,
     w.hdr->n_fallback = 0;
     w.hdr->n_partial = 0;
     w.hdr->partial_off = w.partial_off;
+    w.hdr->count_off = w.count_off;
+    w.hdr->n_cells = 0;
+    w.hdr->n_pruned = 0;
   }
   const int lane = threadIdx.x & 63;
   const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ 
     int T, U;
     utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
     const CellRaw raw = cell_load(w, labels, b, t, u, T, U, jg.maxT, jg.maxU1, jg.V, true);
-    float4 cf = cell_coef(raw);
+    float4 cf = cell_coef(raw, kPruneLog2);  // nothing is re-read here: the fixed default
     const float sc = grad_scale ? grad_scale[b] : 1.f;
     cf.y *= sc;
     cf.z *= sc;

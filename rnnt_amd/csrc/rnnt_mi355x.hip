@@ -46,11 +46,17 @@
 #include "joint.h"
 #include "aux_kernels.h"
 
+#include <atomic>
+
 namespace {
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+
+// Pruning threshold of the gradient kernels (log2 of the occupancy below which a row is zero-filled unread):
+// the library's one process-wide setting, see rnnt_mi355x_set_prune_log2.
+std::atomic<float> g_prune_log2{kPruneLog2};
 
 struct RowCfg {
   int vec, L, nc, g;
@@ -91,6 +97,7 @@ RowCfg pick_row_cfg(int B, int maxT, int maxU1, int V, int blank, const void* p0
   c.gm.nTB = (maxT + TT - 1) / TT;
   c.gm.npass = (cpl + c.nc - 1) / c.nc;
   c.gm.b0 = 0;
+  c.gm.prune_log2 = g_prune_log2.load(std::memory_order_relaxed);
   c.gm.xstride = c.gm.gstride = (size_t)maxT * maxU1 * V;
   c.gm.nblocks = B * c.gm.nTB;
   c.gm.nblocks_all = B * c.gm.nTB;
@@ -173,6 +180,7 @@ SmallGeom small_geom(const Call& c, int* blocks) {
   g.B = c.B; g.maxT = c.maxT; g.maxU1 = c.maxU1; g.V = c.V; g.blank = c.blank;
   g.frames = c.t_off + c.maxT; g.t_off = c.t_off;
   g.total_rows = (long long)c.B * g.frames * c.maxU1;
+  g.prune_log2 = g_prune_log2.load(std::memory_order_relaxed);
   g.ntiles_full = (int)(g.total_rows / 64);
   long long want = (g.ntiles_full + kSmallWaves - 1) / kSmallWaves;
   // persistent grid, exactly one resident round: tiles are dealt round-robin to the waves.  Residency per CU is
@@ -273,16 +281,25 @@ int launch_backward(const Call& c, hipStream_t st) {
   return launch_status();
 }
 
-// forward + backward on the caller's stream.  ev_begin / ev_end (optional hipEvent_t) bracket the gradient
-// launch.  (Running the latency-bound sweep of one half of the batch on a second stream underneath the
-// streaming kernels of the other half was measured and rejected: the sweep is hidden, but two extra kernel
-// tails and its interference cost as much as the 0.1 ms it saves.)
-int launch_loss_grad(const Call& c, hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end) {
-  int rc = launch_forward(c, st);
+// forward + backward on the caller's stream.  ev (optional): four hipEvent_t recorded before k_lse, between k_lse
+// and k_sweep, between k_sweep and k_grad, and after k_grad; null entries are skipped.  (Running the
+// latency-bound sweep of one half of the batch on a second stream underneath the streaming kernels of the other
+// half was measured and rejected: the sweep is hidden, but two extra kernel tails and its interference cost as
+// much as the 0.1 ms it saves.)
+int launch_loss_grad(const Call& c, hipStream_t st, void* const* ev) {
+  auto mark = [&](int i) {
+    return !ev || !ev[i] || hipEventRecord(static_cast<hipEvent_t>(ev[i]), st) == hipSuccess;
+  };
+  k_init<<<1, 64, 0, st>>>(c.w, 0);
+  if (!mark(0)) return RNNT_MI355X_LAUNCH_FAILURE;
+  launch_lse(c, 0, c.B, st);
+  if (!mark(1)) return RNNT_MI355X_LAUNCH_FAILURE;
+  launch_sweep(c, 0, c.B, st);
+  if (!mark(2)) return RNNT_MI355X_LAUNCH_FAILURE;
+  int rc = launch_status();
   if (rc != RNNT_MI355X_OK) return rc;
-  if (ev_begin && hipEventRecord(ev_begin, st) != hipSuccess) return RNNT_MI355X_LAUNCH_FAILURE;
   rc = launch_backward(c, st);
-  if (ev_end && hipEventRecord(ev_end, st) != hipSuccess) return RNNT_MI355X_LAUNCH_FAILURE;
+  if (!mark(3)) return RNNT_MI355X_LAUNCH_FAILURE;
   return rc;
 }
 
@@ -441,7 +458,15 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
 
 extern "C" {
 
-int rnnt_mi355x_version(void) { return 101; }
+int rnnt_mi355x_version(void) { return 102; }
+
+int rnnt_mi355x_set_prune_log2(float log2_threshold) {
+  if (!(log2_threshold <= -16.f)) return RNNT_MI355X_INVALID_VALUE;  // also rejects NaN
+  g_prune_log2.store(log2_threshold, std::memory_order_relaxed);
+  return RNNT_MI355X_OK;
+}
+
+float rnnt_mi355x_get_prune_log2(void) { return g_prune_log2.load(std::memory_order_relaxed); }
 
 const char* rnnt_mi355x_status_string(int status) {
   switch (status) {
@@ -542,19 +567,18 @@ int rnnt_mi355x_loss_grad(float* logits_inout, const int32_t* labels, const int3
                           int B, int maxT, int maxU1, int V, int blank, const float* grad_scale, float* costs,
                           void* workspace, void* hip_stream) {
   return rnnt_mi355x_loss_grad_events(logits_inout, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale,
-                                      costs, workspace, hip_stream, nullptr, nullptr);
+                                      costs, workspace, hip_stream, nullptr);
 }
 
 int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, const int32_t* in_len,
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
                                  const float* grad_scale, float* costs, void* workspace, void* hip_stream,
-                                 void* ev_grad_begin, void* ev_grad_end) {
+                                 void* const* events4) {
   Call c;
   const int rc = make_call(&c, logits_inout, logits_inout, labels, in_len, lab_len, B, maxT, maxU1, V, blank,
                            grad_scale, costs, workspace, true, true);
   if (rc != RNNT_MI355X_OK) return rc;
-  return launch_loss_grad(c, static_cast<hipStream_t>(hip_stream), static_cast<hipEvent_t>(ev_grad_begin),
-                          static_cast<hipEvent_t>(ev_grad_end));
+  return launch_loss_grad(c, static_cast<hipStream_t>(hip_stream), events4);
 }
 
 int rnnt_mi355x_joint_workspace_bytes(int B, int maxT, int maxU1, int V, size_t* out_bytes) {
@@ -594,6 +618,21 @@ int rnnt_mi355x_reduce_scalars(const float* costs, int B, void* workspace, doubl
   k_reduce_scalars<<<1, 1024, 0, static_cast<hipStream_t>(hip_stream)>>>(costs, B, static_cast<const char*>(workspace),
                                                                         out2);
   return launch_status();
+}
+
+int rnnt_mi355x_read_stats(void* workspace, uint64_t* host_cells, uint64_t* host_pruned, void* hip_stream) {
+  if (!workspace || !host_cells || !host_pruned) return RNNT_MI355X_INVALID_VALUE;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  k_reduce_counts<<<1, 1024, 0, st>>>(static_cast<char*>(workspace));
+  if (launch_status() != RNNT_MI355X_OK) return RNNT_MI355X_LAUNCH_FAILURE;
+  uint64_t two[2] = {0, 0};
+  if (hipMemcpyAsync(two, static_cast<const char*>(workspace) + offsetof(Header, n_cells), sizeof(two),
+                     hipMemcpyDeviceToHost, st) != hipSuccess)
+    return RNNT_MI355X_LAUNCH_FAILURE;
+  if (hipStreamSynchronize(st) != hipSuccess) return RNNT_MI355X_LAUNCH_FAILURE;
+  *host_cells = two[0];
+  *host_pruned = two[1];
+  return RNNT_MI355X_OK;
 }
 
 int rnnt_mi355x_read_status(const void* workspace, int32_t* host_flags, void* hip_stream) {

@@ -53,6 +53,7 @@ struct SmallGeom {
   int t_off;             // leading frames of every utterance that take no part in the lattice (a crop along T)
   int ntiles_full;       // tiles of 64 whole rows
   long long total_rows;  // B*frames*maxU1
+  float prune_log2;      // cells with log2 gamma below this get a zero gradient row without being re-read
 };
 
 // b, T, U are in/out: the lengths are reloaded only when the lane's utterance changes (rarely), so that
@@ -258,12 +259,12 @@ __device__ __forceinline__ CellRaw cell_load(const Ws& w, const int32_t* labels,
 }
 
 // {c2, pb, pl, label} of the cell (c2 = -inf: the row's gradient is exactly zero)
-__device__ __forceinline__ float4 cell_coef(const CellRaw& r) {
+__device__ __forceinline__ float4 cell_coef(const CellRaw& r, float prune_log2) {
   float4 cf = make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
   if (r.flags & 1) {
     const double a_ll = r.a - r.ll;
     const float g2 = (float)(a_ll + r.be);  // log2 gamma
-    if (g2 >= kPruneLog2) {
+    if (g2 >= prune_log2) {
       float e_b = -INFINITY;  // 2^-inf = 0: no blank move out of this cell
       if (r.flags & 2) e_b = (float)(a_ll + r.be_t) + r.rc.x;
       else if (r.flags & 4) e_b = (float)a_ll + r.rc.x;
@@ -320,6 +321,9 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
   const f4v* x4 = reinterpret_cast<const f4v*>(x);
   f4v* g4 = reinterpret_cast<f4v*>(grad);
   if (blockIdx.x == 0 && threadIdx.x == 0) w.hdr->n_partial = gridDim.x;
+  __shared__ int tail_cnt[2];  // cells / pruned cells of the last, partial tile (block 0 only)
+  if (threadIdx.x < 2) tail_cnt[threadIdx.x] = 0;
+  __syncthreads();
 
   // rows [row_lo(i), row_hi(i)] of a tile overlap its i-th KiB: that load is needed iff one of them is active
   auto chunk_needed = [&](unsigned long long active, int i) {
@@ -350,6 +354,11 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
   };
 
   float sqsum = 0.f;
+  int n_cell = 0, n_pruned = 0;  // wave-uniform counts of lattice cells seen / pruned
+  auto count = [&](const CellRaw& r, const float4& c) {
+    n_cell += __popcll(__ballot(r.flags & 1));
+    n_pruned += __popcll(__ballot((r.flags & 1) && !(c.x > -INFINITY)));
+  };
   // Tiles are taken in the reverse of k_lse_small's order (most recently read rows first).  Three stages are in
   // flight: the cell state of tile k+2, the logits of tile k+1 (gated by which of its rows are active) and the
   // arithmetic of tile k.
@@ -362,7 +371,8 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
   raw.flags = 0;
   if (k < g.ntiles_full) {
     const CellRaw r0 = raw_of(last - k, sc);
-    cf = cell_coef(r0);
+    cf = cell_coef(r0, g.prune_log2);
+    count(r0, cf);
     active = __ballot(cf.x > -INFINITY);
     issue(last - k, active);
     if (k + nw < g.ntiles_full) raw = raw_of(last - (k + nw), sc_raw);
@@ -377,7 +387,8 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
     const float4 ccf = cf;
     const float csc = sc;
     if (k + nw < g.ntiles_full) {
-      cf = cell_coef(raw);  // loaded one iteration ago
+      cf = cell_coef(raw, g.prune_log2);  // loaded one iteration ago
+      count(raw, cf);
       sc = sc_raw;
       active = __ballot(cf.x > -INFINITY);
       issue(last - (k + nw), active);
@@ -411,7 +422,12 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
     bool in_range;
     small_decode(row, g, in_len, lab_len, b, t, u, T, U, in_range);
     if (row < g.total_rows) {
-      const float4 c = cell_coef(cell_load(w, labels, b, t, u, T, U, g.maxT, g.maxU1, V, in_range));
+      const CellRaw rl = cell_load(w, labels, b, t, u, T, U, g.maxT, g.maxU1, V, in_range);
+      const float4 c = cell_coef(rl, g.prune_log2);
+      if (rl.flags & 1) {  // divergent here: counted per lane, summed below
+        atomicAdd(&tail_cnt[0], 1);
+        if (!(c.x > -INFINITY)) atomicAdd(&tail_cnt[1], 1);
+      }
       float* gp = grad + (size_t)row * V;
       if (c.x > -INFINITY) {
         sqsum += small_row_grad<1>(x + (size_t)row * V, gp, V, g.blank, c, grad_scale ? grad_scale[b] : 1.f);
@@ -421,14 +437,17 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
     }
   }
   __shared__ float red[kSmallWaves];
+  __shared__ int cnt[2][kSmallWaves];
   sqsum = group_sum<64>(sqsum);
-  if (lane == 0) red[wv] = sqsum;
+  if (lane == 0) { red[wv] = sqsum; cnt[0][wv] = n_cell; cnt[1][wv] = n_pruned; }
   __syncthreads();
   if (threadIdx.x == 0) {
     float s = 0.f;
+    uint2 c = make_uint2((unsigned)tail_cnt[0], (unsigned)tail_cnt[1]);
 #pragma unroll
-    for (int i = 0; i < kSmallWaves; ++i) s += red[i];
+    for (int i = 0; i < kSmallWaves; ++i) { s += red[i]; c.x += cnt[0][i]; c.y += cnt[1][i]; }
     w.partial[blockIdx.x] = s;
+    w.pcount[blockIdx.x] = c;
   }
 }
 

@@ -17,7 +17,8 @@ constexpr int kRowBlock = 256;  // threads per block of the streaming kernels
 constexpr int kRowWaves = kRowBlock / 64;
 // Lattice cells whose occupancy gamma = exp(alpha+beta-ll) is below 2^kPruneLog2 (~9e-13) get an exactly zero
 // gradient row: every element of that row is bounded by gamma, far below float32 resolution of any sum it
-// could enter.  Their logits are then not read a second time.
+// could enter.  Their logits are then not read a second time.  This is the default; the threshold in force is a
+// process-wide setting (rnnt_mi355x_set_prune_log2) handed to the gradient kernels as an argument.
 constexpr float kPruneLog2 = -40.f;
 
 // First bytes of the workspace, written on the device.
@@ -26,7 +27,11 @@ struct Header {
   int32_t n_partial;      // entries of `partial` the last k_grad wrote
   uint64_t partial_off;   // byte offset of `partial` from the workspace base
   int32_t n_fallback;     // fused joint: lattice cells whose linear-domain sum underflowed (handled by the exp path)
-  int32_t pad[59];
+  int32_t pad0;
+  uint64_t count_off;     // byte offset of `pcount` from the workspace base
+  uint64_t n_cells;       // written by k_reduce_counts: lattice cells the last gradient pass visited ...
+  uint64_t n_pruned;      // ... and how many of them it pruned
+  int32_t pad[52];
 };
 static_assert(sizeof(Header) == 256, "header is one 256-byte block");
 
@@ -34,6 +39,7 @@ struct Ws {
   Header* hdr;
   double* ll;      // [2][B]  log2-likelihood from alpha / from beta
   float* partial;  // [B*maxT] per-block sum of squared gradient elements
+  uint2* pcount;   // [B*maxT] per-block {lattice cells, cells pruned} of the last gradient pass
   // [B][maxT+2][maxU1] {log2 P(blank|t,u), log2 P(label u+1|t,u), log2-sum-exp2 of the row, 0}; frame t lives at
   // index t+1, frames -1 and maxT are guards.  Every entry that is not a lattice cell (guards, t >= T_b,
   // u > U_b) and the label slot of column U_b hold "log 0", so the sweeps need no masks.
@@ -62,7 +68,7 @@ struct Ws {
   float* dgpart;   // [dg_split][B][maxU1][V] partial d g of each slice of the frames (only when dg_split > 1)
   int dg_split;    // slices the sum over frames of the d g contraction is cut into (1 = written straight to d g)
   int Vp, U1p, Tp; // padded extents: maxT and maxU1 rounded up to 32, V to 32 / 64 / a multiple of 128
-  size_t partial_off;
+  size_t partial_off, count_off;
   int D;    // diagonals = maxT + maxU1 - 1
   int U1s;  // row stride = 64 * sweep_cols_per_lane(maxU1)
 };
@@ -102,6 +108,7 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
   const size_t o_hdr = take(sizeof(Header));
   const size_t o_ll = take(sizeof(double) * 2 * B);
   const size_t o_partial = take(sizeof(float) * (size_t)B * maxT);
+  const size_t o_pcount = take(sizeof(uint2) * (size_t)B * maxT);
   const size_t o_rec = take(sizeof(float4) * (size_t)B * (maxT + 2) * maxU1);
   const size_t o_alpha = take(sizeof(double) * plane);
   const size_t o_beta = take(sizeof(double) * plane);
@@ -127,6 +134,8 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
     w->hdr = reinterpret_cast<Header*>(p + o_hdr);
     w->ll = reinterpret_cast<double*>(p + o_ll);
     w->partial = reinterpret_cast<float*>(p + o_partial);
+    w->pcount = reinterpret_cast<uint2*>(p + o_pcount);
+    w->count_off = o_pcount;
     w->rec = reinterpret_cast<float4*>(p + o_rec);
     w->alpha = reinterpret_cast<double*>(p + o_alpha);
     w->beta = reinterpret_cast<double*>(p + o_beta);
@@ -162,6 +171,7 @@ struct RowGeom {
   int nTB;    // frame blocks per utterance
   int npass;  // passes of NC chunks per lane over one row
   int b0;     // first utterance of this launch
+  float prune_log2;  // cells with log2 gamma below this get a zero gradient row without being re-read
   size_t xstride;   // elements between consecutive utterances of the logits (>= maxT*maxU1*V)
   size_t gstride;   // same for the gradient buffer
   int nblocks;      // blocks of this launch = (utterances of this launch) * nTB

@@ -1,5 +1,12 @@
 """Utterance sharding across the GPUs of one node.
 
+A shard's time is set by what it streams, not by its lattice cells alone: every
+rank pads its utterances to its own longest T and U+1 and the gradient pass
+writes (zero-fills) all of that, so a partition that mixes long and short
+utterances on one rank pays for the padding.  :func:`partition` therefore
+chooses between cell-balanced LPT, a length-bucketed cut and a greedy on a
+measured time model, by the modelled time of the slowest shard.
+
 The reference's only parallelism is in-process batch slicing
 (``multi_gpu_model``, reference rnnt/keras_model.py:203-206, with ``lr /= N``
 and ``batch *= N`` at reference rnnt/base/common.py:177-188).  Utterances are
@@ -37,13 +44,200 @@ def partition_lpt(costs: Sequence[int], n_shards: int) -> List[List[int]]:
     return [sorted(s) for s in shards]
 
 
-def shard_batch(acts, labels, input_lengths, label_lengths, rank: int, world_size: int):
+# Constants of the per-shard time model, measured on one MI355X with the kernels of this library: the first pass
+# reads the logits of every lattice cell, the gradient pass writes every row of the shard's padded tensor and
+# re-reads the rows it does not prune, the two lattice sweeps run T+U dependent steps whose length depends on how
+# many label columns a lane owns.  Only the ratios matter for choosing a partition.
+MODEL_READ_BPS = 6.7e12
+MODEL_WRITE_BPS = 5.4e12
+MODEL_UNPRUNED = 0.5
+MODEL_LAUNCH_S = 20e-6
+
+
+def _sweep_step_s(max_u1: int) -> float:
+    return (60e-9 if max_u1 <= 64 else 92e-9 if max_u1 <= 128 else 226e-9 if max_u1 <= 256 else
+            490e-9 if max_u1 <= 512 else 1000e-9)
+
+
+def shard_seconds(input_lengths: Sequence[int], label_lengths: Sequence[int], indices: Sequence[int], V: int) -> float:
+    """Modelled time of one forward+backward over the utterances `indices`,
+    padded to their own max T and max U+1."""
+    if not indices:
+        return 0.0
+    t_max = max(int(input_lengths[i]) for i in indices)
+    u1_max = max(int(label_lengths[i]) for i in indices) + 1
+    cells = sum(int(input_lengths[i]) * (int(label_lengths[i]) + 1) for i in indices)
+    return _model_seconds(len(indices), t_max, u1_max, cells, V)
+
+
+def _model_seconds(n: int, t_max: int, u1_max: int, cells: int, V: int) -> float:
+    rows = n * t_max * u1_max
+    row_bytes = 4.0 * V
+    return (cells * row_bytes * (1.0 + MODEL_UNPRUNED) / MODEL_READ_BPS + rows * row_bytes / MODEL_WRITE_BPS +
+            (t_max + u1_max) * _sweep_step_s(u1_max) + MODEL_LAUNCH_S)
+
+
+def padded_rows(input_lengths: Sequence[int], label_lengths: Sequence[int], indices: Sequence[int]) -> int:
+    """Rows (b, t, u) of the shard's tensor once padded to its own maxima."""
+    if not indices:
+        return 0
+    return (len(indices) * max(int(input_lengths[i]) for i in indices) *
+            (max(int(label_lengths[i]) for i in indices) + 1))
+
+
+def partition_bucketed(input_lengths: Sequence[int], label_lengths: Sequence[int], n_shards: int, V: int,
+                       sort_by: str = "best") -> List[List[int]]:
+    """Length-bucketed partition: utterances sorted by length and cut into
+    n_shards consecutive runs so that the largest modelled shard time is as
+    small as possible (exact for that order, by dynamic programming over the
+    cut points).  Utterances of similar length share a shard, so little of a
+    shard's padded tensor is padding.  sort_by: "T" (frames), "U" (labels),
+    "cells" (T*(U+1)) or "best" (the best of the three).  Deterministic."""
+    if n_shards < 1:
+        raise ValueError("n_shards must be >= 1")
+    if sort_by == "best":
+        best, best_t = None, None
+        for key in ("T", "U", "cells"):
+            p = partition_bucketed(input_lengths, label_lengths, n_shards, V, key)
+            t = max(shard_seconds(input_lengths, label_lengths, s, V) for s in p)
+            if best_t is None or t < best_t * (1.0 - 1e-9):
+                best, best_t = p, t
+        return best
+    n = len(input_lengths)
+    keys = {"T": lambda i: (-int(input_lengths[i]), -int(label_lengths[i]), i),
+            "U": lambda i: (-int(label_lengths[i]), -int(input_lengths[i]), i),
+            "cells": lambda i: (-int(input_lengths[i]) * (int(label_lengths[i]) + 1), i)}
+    if sort_by not in keys:
+        raise ValueError(f"unknown sort key {sort_by!r}")
+    order = sorted(range(n), key=keys[sort_by])
+    k = min(n_shards, n) if n else 0
+    # cost[a][b] = modelled time of order[a:b], built incrementally
+    cost = [[0.0] * (n + 1) for _ in range(n + 1)]
+    for a in range(n):
+        t_max = u1_max = cells = 0
+        for b in range(a + 1, n + 1):
+            i = order[b - 1]
+            t, u1 = int(input_lengths[i]), int(label_lengths[i]) + 1
+            t_max, u1_max, cells = max(t_max, t), max(u1_max, u1), cells + t * u1
+            cost[a][b] = _model_seconds(b - a, t_max, u1_max, cells, V)
+    inf = float("inf")
+    best = [[inf] * (n + 1) for _ in range(k + 1)]
+    cut = [[0] * (n + 1) for _ in range(k + 1)]
+    if k:
+        best[0][0] = 0.0
+    for s in range(1, k + 1):
+        for b in range(s, n + 1):
+            for a in range(s - 1, b):
+                v = max(best[s - 1][a], cost[a][b])
+                if v < best[s][b]:
+                    best[s][b], cut[s][b] = v, a
+    shards: List[List[int]] = [[] for _ in range(n_shards)]
+    b = n
+    for s in range(k, 0, -1):
+        a = cut[s][b]
+        shards[s - 1] = sorted(order[a:b])
+        b = a
+    return shards
+
+
+def partition_greedy_model(input_lengths: Sequence[int], label_lengths: Sequence[int], n_shards: int, V: int) -> List[List[int]]:
+    """Longest-first greedy on the modelled time: utterances by decreasing T,
+    each given to the shard whose modelled time after taking it is smallest."""
+    if n_shards < 1:
+        raise ValueError("n_shards must be >= 1")
+    order = sorted(range(len(input_lengths)), key=lambda i: (-int(input_lengths[i]), -int(label_lengths[i]), i))
+    shards: List[List[int]] = [[] for _ in range(n_shards)]
+    for i in order:
+        k = min(range(n_shards), key=lambda s: (shard_seconds(input_lengths, label_lengths, shards[s] + [i], V),
+                                                len(shards[s]), s))
+        shards[k].append(i)
+    return [sorted(s) for s in shards]
+
+
+def refine_partition(input_lengths: Sequence[int], label_lengths: Sequence[int], shards: List[List[int]], V: int,
+                     max_rounds: int = 200) -> List[List[int]]:
+    """Local search on a partition: move one utterance out of the slowest shard,
+    or swap it with one of another shard, whenever that lowers the modelled time
+    of the slowest shard (first improvement in a fixed scan order, so the result
+    is deterministic)."""
+    shards = [list(s) for s in shards]
+    n = len(shards)
+
+    def sec(s):
+        return shard_seconds(input_lengths, label_lengths, s, V)
+
+    times = [sec(s) for s in shards]
+    for _ in range(max_rounds):
+        worst = max(range(n), key=lambda k: (times[k], -k))
+        t_worst = times[worst]
+        done = False
+        for i in sorted(shards[worst]):
+            rest = [j for j in shards[worst] if j != i]
+            t_rest = sec(rest)
+            for k in range(n):
+                if k == worst:
+                    continue
+                # move i -> k
+                t_k = sec(shards[k] + [i])
+                if max(t_rest, t_k) < t_worst * (1.0 - 1e-6):
+                    shards[worst], shards[k] = rest, shards[k] + [i]
+                    times[worst], times[k] = t_rest, t_k
+                    done = True
+                    break
+                # swap i <-> j
+                for j in sorted(shards[k]):
+                    a = rest + [j]
+                    b = [m for m in shards[k] if m != j] + [i]
+                    ta, tb = sec(a), sec(b)
+                    if max(ta, tb) < t_worst * (1.0 - 1e-6):
+                        shards[worst], shards[k] = a, b
+                        times[worst], times[k] = ta, tb
+                        done = True
+                        break
+                if done:
+                    break
+            if done:
+                break
+        if not done:
+            break
+    return [sorted(s) for s in shards]
+
+
+def partition(input_lengths: Sequence[int], label_lengths: Sequence[int], n_shards: int, V: int = 1024,
+              method: str = "auto") -> List[List[int]]:
+    """The partition every rank derives for itself (no communication):
+    "cells" = LPT on lattice cells, "bucketed" = partition_bucketed, "greedy" =
+    partition_greedy_model, "auto" = whichever of the three has the smallest
+    modelled slowest shard (ties: in that order), then improved by
+    refine_partition."""
+    il = [int(v) for v in input_lengths]
+    ll = [int(v) for v in label_lengths]
+    cands = {
+        "cells": lambda: partition_lpt(lattice_cost(il, ll), n_shards),
+        "bucketed": lambda: partition_bucketed(il, ll, n_shards, V),
+        "greedy": lambda: partition_greedy_model(il, ll, n_shards, V),
+    }
+    if method != "auto":
+        if method not in cands:
+            raise ValueError(f"unknown partition method {method!r}")
+        return cands[method]()
+    best, best_t = None, None
+    for name in ("cells", "bucketed", "greedy"):
+        p = cands[name]()
+        t = max(shard_seconds(il, ll, s, V) for s in p)
+        if best_t is None or t < best_t * (1.0 - 1e-9):
+            best, best_t = p, t
+    return refine_partition(il, ll, best, V)
+
+
+def shard_batch(acts, labels, input_lengths, label_lengths, rank: int, world_size: int, method: str = "auto"):
     """This rank's slice of a batch, cropped to the shard's own max T and U+1
     (each rank pads only to its local maxima).  Returns (acts, labels, in_len,
     lab_len, indices); acts is a fresh contiguous tensor when cropped."""
     il = [int(v) for v in torch.as_tensor(input_lengths).reshape(-1).tolist()]
     ll = [int(v) for v in torch.as_tensor(label_lengths).reshape(-1).tolist()]
-    idx = partition_lpt(lattice_cost(il, ll), world_size)[rank]
+    V = int(acts.shape[-1]) if hasattr(acts, "shape") else 1024
+    idx = partition(il, ll, world_size, V, method)[rank]
     if not idx:
         return None, None, None, None, idx
     sel = torch.as_tensor(idx, dtype=torch.long, device=acts.device if isinstance(acts, torch.Tensor) else None)

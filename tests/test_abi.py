@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_version_and_status_strings():
-    assert _lib.lib().rnnt_mi355x_version() == 101
+    assert _lib.lib().rnnt_mi355x_version() == 102
     assert _lib.status_string(0) == "ok"
     for rc in (1, 2, 3, 4, 99):
         assert _lib.status_string(rc)
@@ -58,6 +58,19 @@ def test_null_and_range_arguments_are_rejected_before_any_launch():
     assert L.rnnt_mi355x_backward(one, None, one, one, one, 1, 2, 2, 4, 0, None, one, None) == _lib.INVALID_VALUE
     assert L.rnnt_mi355x_loss_grad(one, one, one, one, 1, 2, 1100, 4, 0, None, one, one, None) == _lib.UNSUPPORTED_SIZE
     assert L.rnnt_mi355x_reduce_scalars(None, 1, one, one, None) == _lib.INVALID_VALUE
+
+
+def test_prune_threshold_setting():
+    L = _lib.lib()
+    one = ctypes.c_void_p(256)  # never dereferenced: validation fails first
+    assert L.rnnt_mi355x_get_prune_log2() == -40.0
+    assert L.rnnt_mi355x_set_prune_log2(-8.0) == _lib.INVALID_VALUE       # would show at the 1e-4 bar
+    assert L.rnnt_mi355x_set_prune_log2(float("nan")) == _lib.INVALID_VALUE
+    assert L.rnnt_mi355x_set_prune_log2(-28.0) == _lib.OK
+    assert L.rnnt_mi355x_get_prune_log2() == -28.0
+    assert L.rnnt_mi355x_set_prune_log2(float("-inf")) == _lib.OK          # pruning off
+    assert L.rnnt_mi355x_set_prune_log2(-40.0) == _lib.OK
+    assert L.rnnt_mi355x_read_stats(None, None, None, None) == _lib.INVALID_VALUE
 
 
 def test_python_layer_refuses_cpu_tensors():

@@ -144,6 +144,45 @@ def test_pruned_rows_are_truly_negligible():
     assert np.abs(g - go).max() < 2e-5
 
 
+@pytest.mark.parametrize("V,blank", [(64, 63), (256, 0)])
+def test_prune_threshold_is_a_runtime_setting_and_is_counted(V, blank):
+    """rnnt_mi355x_set_prune_log2 moves the occupancy threshold of the gradient pass (both the row-per-lane and the
+    lanes-per-row kernels), rnnt_mi355x_read_stats counts what it pruned; every pruned row's exact gradient is
+    bounded by the threshold, and with pruning off the result is the dense one."""
+    import ctypes
+    from rnnt_amd import _lib
+    from tests.hip_runner import _p
+    B, T, U = 2, 240, 60
+    x, lab, il, ll = _gpu_batch(B, T, U, V, blank, seed=17)
+    il[1], ll[1] = 200, 41
+    xh = x.cpu().numpy()
+    _, go = orc.rnnt_loss_and_grad(xh, lab.cpu().numpy(), il, ll, blank)
+    cells_expected = int((il.astype(np.int64) * (ll.astype(np.int64) + 1)).sum())
+    L = _lib.lib()
+    fracs = {}
+    try:
+        for thr in (float("-inf"), -40.0, -24.0, -16.0):
+            assert L.rnnt_mi355x_set_prune_log2(thr) == 0
+            run = _run(x.clone(), lab, il, ll, blank)
+            cells, pruned = _lib.read_stats(_p(run.ws), run.stream)
+            assert cells == cells_expected
+            g = run.x.cpu().numpy()
+            lattice = np.zeros(g.shape[:3], bool)
+            for b in range(B):
+                lattice[b, :il[b], :ll[b] + 1] = True
+            zero_rows = ~g.any(-1) & lattice
+            if thr > float("-inf"):  # (with pruning off, far-off rows still underflow to zeros)
+                assert zero_rows.sum() == pruned
+            fracs[thr] = pruned / cells
+            if pruned:
+                assert np.abs(go[zero_rows]).max() <= 2.0 ** thr * 1.001
+            assert np.abs(g - go).max() < 2e-5 + 2.0 ** thr
+    finally:
+        assert L.rnnt_mi355x_set_prune_log2(-40.0) == 0
+    assert fracs[float("-inf")] == 0.0
+    assert fracs[-40.0] > 0.1 and fracs[-16.0] > fracs[-24.0] > fracs[-40.0]
+
+
 @pytest.mark.parametrize("B,T,U,V,blank", [(32, 500, 100, 62, 39), (16, 400, 100, 1024, 1023)])
 def test_fused_joint_full_size_equals_materialised_path(B, T, U, V, blank):
     """BASELINE shapes 2 and 3 (a quarter of config 3's batch): the additive-joint path (matrix-core

@@ -12,6 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import rnnt_oracle as orc
+from rnnt_amd import sharding
 from rnnt_amd.sharding import allreduce_scalars, lattice_cost, partition_lpt, shard_batch
 
 
@@ -103,3 +104,51 @@ def test_allreduce_is_identity_without_process_group():
     t = torch.tensor([1.5, 2.5], dtype=torch.float64)
     assert allreduce_scalars(t) is t
     assert allreduce_scalars(t, async_op=True) is None
+
+
+def _ragged_lengths(seed, B=128):
+    rng = np.random.default_rng(seed)
+    return rng.integers(50, 1001, B).tolist(), rng.integers(10, 201, B).tolist()
+
+
+@pytest.mark.parametrize("method", ["cells", "bucketed", "greedy", "auto"])
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
+def test_every_partitioner_covers_each_utterance_once_and_is_deterministic(method, n):
+    il, ll = _ragged_lengths(7, B=50)
+    p1 = sharding.partition(il, ll, n, 512, method)
+    p2 = sharding.partition(list(il), list(ll), n, 512, method)
+    assert p1 == p2
+    assert len(p1) == n
+    assert sorted(i for s in p1 for i in s) == list(range(50))
+    assert all(s == sorted(s) for s in p1)
+
+
+def test_partitioners_handle_fewer_utterances_than_shards():
+    for method in ("cells", "bucketed", "greedy", "auto"):
+        p = sharding.partition([100, 50, 70], [10, 5, 7], 8, 512, method)
+        assert sorted(i for s in p for i in s) == [0, 1, 2] and len(p) == 8
+
+
+def test_length_aware_partition_streams_less_padding_than_cell_balanced_lpt():
+    """Ragged batch of the B=128, T in [50,1000], U in [10,200] configuration on 8 ranks: balancing lattice cells
+    puts long and short utterances on one rank, whose padded tensor (what the gradient pass writes) then is mostly
+    padding; the default partition must cut both the padded volume and the modelled slowest rank."""
+    il, ll = _ragged_lengths(0xC0FFEE + 7)
+    lpt = sharding.partition(il, ll, 8, 512, "cells")
+    auto = sharding.partition(il, ll, 8, 512, "auto")
+    rows = lambda p: [sharding.padded_rows(il, ll, s) for s in p]
+    secs = lambda p: max(sharding.shard_seconds(il, ll, s, 512) for s in p)
+    assert sum(rows(auto)) < 0.75 * sum(rows(lpt))
+    assert max(rows(auto)) < 0.9 * max(rows(lpt))
+    assert secs(auto) < 0.85 * secs(lpt)
+    # uniform lengths: nothing to gain, equal counts
+    assert [len(s) for s in sharding.partition([400] * 64, [100] * 64, 8, 1024, "auto")] == [8] * 8
+
+
+def test_refinement_never_makes_the_slowest_shard_slower():
+    il, ll = _ragged_lengths(3, B=40)
+    base = sharding.partition(il, ll, 4, 512, "cells")
+    ref = sharding.refine_partition(il, ll, base, 512)
+    worst = lambda p: max(sharding.shard_seconds(il, ll, s, 512) for s in p)
+    assert worst(ref) <= worst(base)
+    assert sorted(i for s in ref for i in s) == list(range(40))

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Pruning-threshold study of the gradient pass on a config-3-shaped batch:
+for each threshold the fraction of lattice rows pruned, the largest change of a
+gradient element and of the downstream sums over u and over t (what the
+encoder / prediction network see) against the un-pruned run, and the step
+time.  Inputs: logits ~ N(0,1) and ~ N(0,1)*10.  grad_scale = 1."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from rnnt_amd import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=16)
+    ap.add_argument("--T", type=int, default=400)
+    ap.add_argument("--U", type=int, default=100)
+    ap.add_argument("--V", type=int, default=1024)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    B, T, U1, V, blank = a.B, a.T, a.U + 1, a.V, a.V - 1
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    base = torch.empty((B, T, U1, V), device=dev).normal_(generator=gen)
+    labels = torch.randint(0, V - 1, (B, a.U), generator=gen, device=dev, dtype=torch.int32)
+    il = torch.full((B,), T, dtype=torch.int32, device=dev)
+    ll = torch.full((B,), a.U, dtype=torch.int32, device=dev)
+    costs = torch.empty(B, device=dev)
+    ws = torch.empty(_lib.workspace_bytes(B, T, U1), dtype=torch.uint8, device=dev)
+    sp = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    buf = torch.empty_like(base)
+    rows = []
+    for scale in (1.0, 10.0):
+        master = base * scale
+        ref = None
+        for thr in (float("-inf"), -40.0, -32.0, -28.0, -24.0, -20.0, -16.0):
+            assert L.rnnt_mi355x_set_prune_log2(thr) == 0
+            ms = []
+            for _ in range(a.reps):
+                buf.copy_(master)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = L.rnnt_mi355x_loss_grad(p(buf), p(labels), p(il), p(ll), B, T, U1, V, blank, None, p(costs), p(ws), sp)
+                e1.record()
+                torch.cuda.synchronize()
+                assert rc == 0
+                ms.append(e0.elapsed_time(e1))
+            cells, pruned = _lib.read_stats(p(ws), sp)
+            if ref is None:
+                ref = buf.clone()
+                d = du = dt = 0.0
+            else:
+                diff = buf - ref
+                d = diff.abs().max().item()
+                du = diff.sum(2).abs().max().item()
+                dt = diff.sum(1).abs().max().item()
+                del diff
+            rows.append({"logit_scale": scale, "prune_log2": thr, "pruned_row_frac": pruned / cells,
+                         "max_abs_dgrad": d, "max_abs_dsum_over_u": du, "max_abs_dsum_over_t": dt,
+                         "step_ms_min": min(ms), "step_ms_median": sorted(ms)[len(ms) // 2],
+                         "mean_cost": costs.mean().item()})
+            print(json.dumps(rows[-1]), flush=True)
+    L.rnnt_mi355x_set_prune_log2(-40.0)
+
+
+if __name__ == "__main__":
+    main()
