@@ -32,7 +32,8 @@
  *     (a hipStream_t, NULL = default stream; its device must be the current
  *     one) and, except rnnt_mi355x_read_status / rnnt_mi355x_read_stats, none
  *     synchronises; the only state the library keeps between calls is the
- *     pruning threshold of rnnt_mi355x_set_prune_log2;
+ *     pruning threshold of rnnt_mi355x_set_prune_log2 and, per device, the
+ *     address of the built-in workspace of rnnt_mi355x_loss_grad_static;
  *   - every function returns an rnnt_mi355x_status; nothing throws or aborts.
  *
  * Limits: 1 <= maxU1 <= 1024, B*maxT*maxU1 < 2^31, (maxT+2)*maxU1 < 2^28,
@@ -135,6 +136,29 @@ int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, con
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
                                  const float* grad_scale, float* costs, void* workspace, void* hip_stream,
                                  void* const* events4);
+
+/* rnnt_mi355x_loss_grad for callers that cannot allocate or own device
+ * scratch memory: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  It has no counterpart in the reference.  The
+ * workspace is an array inside the library's code object
+ * (RNNT_MI355X_STATIC_WORKSPACE_BYTES; every GPU the library runs on holds one
+ * copy until the process ends), so the call takes no workspace and calls no
+ * hipMalloc / hipFree or any other allocating routine.  Shapes whose
+ * rnnt_mi355x_workspace_bytes exceeds that size are rejected with
+ * RNNT_MI355X_UNSUPPORTED_SIZE.  Optional device outputs replace the calls
+ * that would need the workspace pointer: scalars2 (2 doubles: what
+ * rnnt_mi355x_reduce_scalars returns) and flags_out (int32: the validation
+ * word of rnnt_mi355x_read_status); either may be NULL.  All calls on one GPU
+ * share that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race; calls on one stream are ordered and need no clearing in
+ * between (every word the kernels read is written by the same call).  The
+ * first call on a device looks the array's address up
+ * (hipGetSymbolAddress); make it outside graph capture. */
+#define RNNT_MI355X_STATIC_WORKSPACE_BYTES (32u << 20)
+int rnnt_mi355x_loss_grad_static(float* logits_inout, const int32_t* labels, const int32_t* in_len,
+                                 const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
+                                 const float* grad_scale, float* costs, double* scalars2, int32_t* flags_out,
+                                 void* hip_stream);
 
 /* ---- fused additive joint ------------------------------------------------
  * The loss of the reference's additive-joint model, Util.rnnt_lambda_func

@@ -20,6 +20,7 @@ LAUNCH_FAILURE = 3
 BAD_INPUT_DATA = 4
 FLAG_BAD_LENGTH = 1
 FLAG_BAD_LABEL = 2
+STATIC_WORKSPACE_BYTES = 32 << 20  # RNNT_MI355X_STATIC_WORKSPACE_BYTES
 
 _lib = None
 
@@ -37,6 +38,7 @@ _SIGNATURES = {
     "rnnt_mi355x_backward_inplace": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp]),
     "rnnt_mi355x_loss_grad": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp]),
     "rnnt_mi355x_loss_grad_events": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
+    "rnnt_mi355x_loss_grad_static": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp, _vp]),
     "rnnt_mi355x_set_prune_log2": (ctypes.c_int, [ctypes.c_float]),
     "rnnt_mi355x_get_prune_log2": (ctypes.c_float, []),
     "rnnt_mi355x_read_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), _vp]),

@@ -47,6 +47,7 @@
 #include "aux_kernels.h"
 
 #include <atomic>
+#include <mutex>
 
 namespace {
 
@@ -323,6 +324,29 @@ int make_call(Call* c, const float* logits, float* grad, const int32_t* labels, 
   return RNNT_MI355X_OK;
 }
 
+// ---- the entry point that allocates nothing ----
+// Its workspace is this array of the code object instead of a caller's buffer: every GPU the library runs on holds
+// one copy for the life of the process.  `scratch` itself is a host-side stand-in; the address the kernels get is
+// the one hipGetSymbolAddress reports for the current device, looked up once per device.
+__device__ __align__(256) unsigned char scratch[RNNT_MI355X_STATIC_WORKSPACE_BYTES];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+int scratch_of_current_device(void** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return RNNT_MI355X_LAUNCH_FAILURE;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return RNNT_MI355X_LAUNCH_FAILURE;
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return RNNT_MI355X_OK;
+}
+
 // ---- fused additive joint: host side ----
 struct JointCall {
   const float* f;
@@ -579,6 +603,34 @@ int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, con
                            grad_scale, costs, workspace, true, true);
   if (rc != RNNT_MI355X_OK) return rc;
   return launch_loss_grad(c, static_cast<hipStream_t>(hip_stream), events4);
+}
+
+int rnnt_mi355x_loss_grad_static(float* logits_inout, const int32_t* labels, const int32_t* in_len,
+                                 const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
+                                 const float* grad_scale, float* costs, double* scalars2, int32_t* flags_out,
+                                 void* hip_stream) {
+  int rc = check_shape(B, maxT, maxU1, V, blank);
+  if (rc != RNNT_MI355X_OK) return rc;
+  if (ws_layout(nullptr, B, maxT, maxU1, nullptr) > (size_t)RNNT_MI355X_STATIC_WORKSPACE_BYTES)
+    return RNNT_MI355X_UNSUPPORTED_SIZE;
+  void* ws = nullptr;
+  rc = scratch_of_current_device(&ws);
+  if (rc != RNNT_MI355X_OK) return rc;
+  Call c;
+  rc = make_call(&c, logits_inout, logits_inout, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale, costs,
+                 ws, true, true);
+  if (rc != RNNT_MI355X_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  rc = launch_loss_grad(c, st, nullptr);
+  if (rc != RNNT_MI355X_OK) return rc;
+  if (scalars2) {
+    k_reduce_scalars<<<1, 1024, 0, st>>>(costs, B, static_cast<const char*>(ws), scalars2);
+    rc = launch_status();
+    if (rc != RNNT_MI355X_OK) return rc;
+  }
+  if (flags_out && hipMemcpyAsync(flags_out, ws, sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return RNNT_MI355X_LAUNCH_FAILURE;
+  return RNNT_MI355X_OK;
 }
 
 int rnnt_mi355x_joint_workspace_bytes(int B, int maxT, int maxU1, int V, size_t* out_bytes) {

@@ -60,7 +60,7 @@ def test_null_and_range_arguments_are_rejected_before_any_launch():
     assert L.rnnt_mi355x_reduce_scalars(None, 1, one, one, None) == _lib.INVALID_VALUE
 
 
-def test_prune_threshold_setting():
+def test_prune_threshold_setting_and_static_entry_point_validation():
     L = _lib.lib()
     one = ctypes.c_void_p(256)  # never dereferenced: validation fails first
     assert L.rnnt_mi355x_get_prune_log2() == -40.0
@@ -70,6 +70,11 @@ def test_prune_threshold_setting():
     assert L.rnnt_mi355x_get_prune_log2() == -28.0
     assert L.rnnt_mi355x_set_prune_log2(float("-inf")) == _lib.OK          # pruning off
     assert L.rnnt_mi355x_set_prune_log2(-40.0) == _lib.OK
+    # the entry point with the built-in workspace rejects what does not fit it, before touching a GPU
+    assert _lib.workspace_bytes(8, 150, 41) < _lib.STATIC_WORKSPACE_BYTES < _lib.workspace_bytes(64, 400, 101)
+    f = L.rnnt_mi355x_loss_grad_static
+    assert f(one, one, one, one, 64, 400, 101, 1024, 0, None, one, None, None, None) == _lib.UNSUPPORTED_SIZE
+    assert f(one, one, one, one, 1, 2, 2, 4, 4, None, one, None, None, None) == _lib.INVALID_VALUE   # blank outside [0,V)
     assert L.rnnt_mi355x_read_stats(None, None, None, None) == _lib.INVALID_VALUE
 
 
