@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = [os.path.join(CSRC, "rnnt_mi355x.hip"), os.path.join(CSRC, "fc_joint.hip"),
            os.path.join(CSRC, "skinny_dense.hip"), os.path.join(CSRC, "decode_step.hip")]
 # rnnt_mi355x.hip is one translation unit whose kernels live in these included pieces
-PIECES = [os.path.join(CSRC, n) for n in ("workspace.h", "device_util.h", "lse_rows.h", "sweep.h", "grad_rows.h",
+PIECES = [os.path.join(CSRC, n) for n in ("workspace.h", "device_util.h", "lse_rows.h", "sweep.h", "grad_rows.h", "grad_span.h",
                                           "small_vocab.h", "joint.h", "aux_kernels.h")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rnnt_mi355x.h")
 LIB = os.path.join(CSRC, "librnnt_mi355x.so")
@@ -34,13 +34,16 @@ def needs_build() -> bool:
     return any(os.path.getmtime(p) > t for p in (*SOURCES, *PIECES, HEADER))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, defines=(), out: str = LIB) -> str:
+    """defines / out: experiment builds (`-DNAME=VALUE` variants of the library under another file name, selected
+    at run time with RNNT_MI355X_LIB)."""
+    if not force and not needs_build() and out == LIB:
         return LIB
     hipcc = hipcc_path()
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", *[f"-D{d}" for d in defines]]
     # one object per source, compiled side by side (objects live next to the library, git-ignored), then one link
-    objs = [os.path.splitext(src)[0] + ".o" for src in SOURCES]
+    tag = "" if out == LIB else "." + os.path.splitext(os.path.basename(out))[0]
+    objs = [os.path.splitext(src)[0] + tag + ".o" for src in SOURCES]
     cmds = [[hipcc, *flags, "-c", src, "-o", obj] for src, obj in zip(SOURCES, objs)]
     if verbose:
         for cmd in cmds:
@@ -49,13 +52,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     failed = [cmd for cmd, pr in zip(cmds, procs) if pr.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
     for obj in objs:
         os.remove(obj)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -54,6 +54,32 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
   }
 }
 
+// Plain (cached, write-back) forms of the same accesses.
+template <int VEC>
+__device__ __forceinline__ void load_vec_plain(const float* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const f4v q = *reinterpret_cast<const f4v*>(p);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  } else if constexpr (VEC == 2) {
+    const f2v q = *reinterpret_cast<const f2v*>(p);
+    v[0] = q.x; v[1] = q.y;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec_plain(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    f4v q = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f4v*>(p) = q;
+  } else if constexpr (VEC == 2) {
+    f2v q = {v[0], v[1]};
+    *reinterpret_cast<f2v*>(p) = q;
+  } else {
+    *p = v[0];
+  }
+}
+
 // All-reduce inside aligned groups of L lanes.  The steps inside a row of 16
 // lanes are DPP operand modifiers (quad swaps, half-row mirror, row mirror:
 // one VALU instruction each, no LDS); only the 16- and 32-lane steps go

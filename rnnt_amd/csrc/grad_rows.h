@@ -21,6 +21,23 @@ namespace {
 // that the rows k_lse read last (still in the memory-side cache) are re-read
 // first.
 // ---------------------------------------------------------------------------
+// Compile-time tuning knobs of k_grad (experiments build variants of the library with -D...).
+#ifndef RNNT_GRAD_ZERO_PLAIN   // zero rows leave through plain stores instead of non-temporal ones
+#define RNNT_GRAD_ZERO_PLAIN 0
+#endif
+#ifndef RNNT_GRAD_STORE_PLAIN  // gradient rows leave through plain stores
+#define RNNT_GRAD_STORE_PLAIN 0
+#endif
+#ifndef RNNT_GRAD_LOAD_PLAIN   // the second read of the logits uses plain loads
+#define RNNT_GRAD_LOAD_PLAIN 0
+#endif
+#ifndef RNNT_GRAD_FWD_ORDER    // blocks in k_lse's order instead of the reverse
+#define RNNT_GRAD_FWD_ORDER 0
+#endif
+#ifndef RNNT_GRAD_WAVES        // waves per SIMD the register allocation aims at
+#define RNNT_GRAD_WAVES 8
+#endif
+
 template <int VEC, int NC, int G>
 struct GradTile {
   float v[G][NC][VEC];
@@ -30,7 +47,7 @@ struct GradTile {
 };
 
 template <int VEC, int L, int NC, int G>
-__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(8))) void k_grad(const float* x, float* grad, const int32_t* __restrict__ labels,
+__global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(RNNT_GRAD_WAVES))) void k_grad(const float* x, float* grad, const int32_t* __restrict__ labels,
                                                     const int32_t* __restrict__ in_len,
                                                     const int32_t* __restrict__ lab_len,
                                                     const float* __restrict__ grad_scale, RowGeom gm, Ws w) {
@@ -38,7 +55,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(8))) 
   constexpr int S = kRowWaves * G * R;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = lane % L, r = lane / L;
-  const int bid = gm.nblocks - 1 - (int)blockIdx.x;
+  const int bid = RNNT_GRAD_FWD_ORDER ? (int)blockIdx.x : gm.nblocks - 1 - (int)blockIdx.x;
   const int bl = bid / gm.nTB;  // utterance within this launch
   const int b = gm.b0 + bl;
   const int t0 = (bid - bl * gm.nTB) * gm.TT;
@@ -121,7 +138,8 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(8))) 
       for (int i = 0; i < NC; ++i) {
         const int c = j + L * (cur.pass * NC + i);
         if (active && c < nchunk) {
-          load_vec<VEC>(rp + (size_t)c * VEC, tl.v[g][i]);
+          if constexpr (RNNT_GRAD_LOAD_PLAIN) load_vec_plain<VEC>(rp + (size_t)c * VEC, tl.v[g][i]);
+          else load_vec<VEC>(rp + (size_t)c * VEC, tl.v[g][i]);
         } else {
 #pragma unroll
           for (int q = 0; q < VEC; ++q) tl.v[g][i][q] = 0.f;
@@ -153,11 +171,14 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(8))) 
               sqsum = __builtin_fmaf(gv, gv, sqsum);
               o[q] = gv;
             }
+            if constexpr (RNNT_GRAD_STORE_PLAIN) store_vec_plain<VEC>(gp + (size_t)c * VEC, o);
+            else store_vec<VEC>(gp + (size_t)c * VEC, o);
           } else {
 #pragma unroll
             for (int q = 0; q < VEC; ++q) o[q] = 0.f;
+            if constexpr (RNNT_GRAD_ZERO_PLAIN) store_vec_plain<VEC>(gp + (size_t)c * VEC, o);
+            else store_vec<VEC>(gp + (size_t)c * VEC, o);
           }
-          store_vec<VEC>(gp + (size_t)c * VEC, o);
         }
       }
     }

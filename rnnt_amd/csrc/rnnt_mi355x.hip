@@ -27,7 +27,7 @@
 // included below:
 //   workspace.h      constants, workspace header and layout
 //   device_util.h    exp2/log2, vector loads, DPP reductions, row cursor
-//   lse_rows.h       k_lse                 grad_rows.h   k_grad
+//   lse_rows.h       k_lse                 grad_rows.h   k_grad (any row)   grad_span.h  k_grad_span (aligned rows <= 4096)
 //   sweep.h          k_sweep               small_vocab.h V <= 128 variants of both passes
 //   joint.h          additive joint fused into the loss (matrix-core contractions)
 //   aux_kernels.h    zero-fill of cropped frames, workspace init, batch scalars
@@ -42,6 +42,7 @@
 #include "lse_rows.h"
 #include "sweep.h"
 #include "grad_rows.h"
+#include "grad_span.h"
 #include "small_vocab.h"
 #include "joint.h"
 #include "aux_kernels.h"
@@ -86,7 +87,10 @@ RowCfg pick_row_cfg(int B, int maxT, int maxU1, int V, int blank, const void* p0
   c.g = 4 / c.nc;
   const int rows_per_iter = kRowWaves * c.g * (64 / c.L);
   // frames per block: about 24 tiles per wave, so that the pipeline fill/drain is amortised
-  int TT = (24 * rows_per_iter + maxU1 - 1) / maxU1;
+#ifndef RNNT_ROW_TILES
+#define RNNT_ROW_TILES 24
+#endif
+  int TT = (RNNT_ROW_TILES * rows_per_iter + maxU1 - 1) / maxU1;
   while (TT > 1 && TT * maxU1 > 2048) --TT;  // the block's records are staged in LDS (<= 32 KiB)
   if (TT < 1) TT = 1;
   if (TT > maxT) TT = maxT;
@@ -266,6 +270,31 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
     k_zero_frames<<<dim3(per_b, (unsigned)c.B), 256, 0, st>>>(c.grad - n, c.gstride, n);
   }
   const RowCfg cfg = sub_cfg(c, c.grad, b0, nb);
+#ifndef RNNT_NO_SPAN
+  if (cfg.vec == 4 && c.V > 128 && c.V <= 4096) {
+    // rows per wave chosen so that a wave owns about 32 KiB: lanes per row L, 16-byte chunks per lane NC, row groups NG
+    SpanGeom sg;
+    sg.maxT = c.maxT; sg.maxU1 = c.maxU1; sg.V = c.V; sg.blank = c.blank;
+    sg.rows_utt = c.maxT * c.maxU1;
+    sg.b0 = b0;
+    sg.prune_log2 = g_prune_log2.load(std::memory_order_relaxed);
+    sg.xstride = c.xstride; sg.gstride = c.gstride;
+    const int nchunk = c.V / 4;
+    auto go = [&](auto kernel, int rows_per_block) {
+      sg.nchunks = (sg.rows_utt + rows_per_block - 1) / rows_per_block;
+      sg.nblocks = nb * sg.nchunks;
+      sg.nblocks_all = c.B * sg.nchunks;
+      kernel<<<dim3((unsigned)sg.nblocks), dim3(kSpanWaves * 64), 0, st>>>(c.logits, c.grad, c.labels, c.in_len, c.lab_len,
+                                                                          c.grad_scale, sg, c.w);
+    };
+    if (nchunk <= 64) go(k_grad_span<16, 4, RNNT_SPAN_NG>, kSpanWaves * RNNT_SPAN_NG * 4);
+    else if (nchunk <= 128) go(k_grad_span<32, 4, RNNT_SPAN_NG>, kSpanWaves * RNNT_SPAN_NG * 2);
+    else if (nchunk <= 256) go(k_grad_span<64, 4, RNNT_SPAN_NG>, kSpanWaves * RNNT_SPAN_NG);
+    else if (nchunk <= 512) go(k_grad_span<64, 8, RNNT_SPAN_NG / 2>, kSpanWaves * (RNNT_SPAN_NG / 2));
+    else go(k_grad_span<64, 16, RNNT_SPAN_NG / 4>, kSpanWaves * (RNNT_SPAN_NG / 4));
+    return;
+  }
+#endif
   RNNT_DISPATCH(k_grad, cfg, sizeof(float4) * (size_t)cfg.gm.TT * c.maxU1, c.logits, c.grad, c.labels, c.in_len,
                 c.lab_len, c.grad_scale, cfg.gm, c.w);
 }

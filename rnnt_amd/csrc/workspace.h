@@ -38,8 +38,8 @@ static_assert(sizeof(Header) == 256, "header is one 256-byte block");
 struct Ws {
   Header* hdr;
   double* ll;      // [2][B]  log2-likelihood from alpha / from beta
-  float* partial;  // [B*maxT] per-block sum of squared gradient elements
-  uint2* pcount;   // [B*maxT] per-block {lattice cells, cells pruned} of the last gradient pass
+  float* partial;  // per-block sum of squared gradient elements (B * max(maxT, maxT*maxU1/16 + 1) slots)
+  uint2* pcount;   // per-block {lattice cells, cells pruned} of the last gradient pass (same number of slots)
   // [B][maxT+2][maxU1] {log2 P(blank|t,u), log2 P(label u+1|t,u), log2-sum-exp2 of the row, 0}; frame t lives at
   // index t+1, frames -1 and maxT are guards.  Every entry that is not a lattice cell (guards, t >= T_b,
   // u > U_b) and the label slot of column U_b hold "log 0", so the sweeps need no masks.
@@ -107,8 +107,10 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
   };
   const size_t o_hdr = take(sizeof(Header));
   const size_t o_ll = take(sizeof(double) * 2 * B);
-  const size_t o_partial = take(sizeof(float) * (size_t)B * maxT);
-  const size_t o_pcount = take(sizeof(uint2) * (size_t)B * maxT);
+  // one entry per block of the gradient pass: blocks of TT >= 1 frames, or of >= 16 rows (k_grad_span)
+  const size_t n_part = (size_t)B * (size_t)((maxT > ((size_t)maxT * maxU1 + 15) / 16 + 1) ? maxT : ((size_t)maxT * maxU1 + 15) / 16 + 1);
+  const size_t o_partial = take(sizeof(float) * n_part);
+  const size_t o_pcount = take(sizeof(uint2) * n_part);
   const size_t o_rec = take(sizeof(float4) * (size_t)B * (maxT + 2) * maxU1);
   const size_t o_alpha = take(sizeof(double) * plane);
   const size_t o_beta = take(sizeof(double) * plane);
