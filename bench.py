@@ -193,7 +193,7 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong: the configuration's one global batch sharded over the ranks; weak: a full batch per rank")
     ap.add_argument("--partition", default="auto", help="cells | bucketed | greedy | auto (rnnt_amd.sharding.partition)")
-    ap.add_argument("--prune-log2", type=float, default=None, help="pruning threshold of the gradient pass (library default -40)")
+    ap.add_argument("--prune-log2", type=float, default=None, help="pruning threshold of the gradient pass (library default -28)")
     ap.add_argument("--logit-scale", type=float, default=1.0, help="logits ~ N(0,1) * scale")
     ap.add_argument("--graph", action="store_true",
                     help="replay each step from a captured HIP graph (kernel times then come from a separate instrumented pass)")
@@ -439,7 +439,7 @@ def run_rank(args) -> None:
     if os.path.exists(tpath) and world == 1 and args.logit_scale == 1.0:
         try:
             ent = json.load(open(tpath)).get(f"config{args.config}", {})
-            if ent.get("B") == B and ent.get("prune_log2", -40.0) == prune_log2:
+            if ent.get("B") == B and ent.get("prune_log2") == prune_log2:
                 counter = ent
         except Exception:
             counter = {}

@@ -243,7 +243,7 @@ int rnnt_mi355x_reduce_scalars(const float* costs, int B, void* workspace, doubl
  * gamma = P(path through (t,u) | labels) is below 2^log2_threshold: every
  * element of such a row's gradient is bounded by grad_scale*gamma, so the row
  * is written as exact zeros and its logits are not read a second time.
- * Default -40 (9e-13); accepted range [-inf, -16] (-inf: nothing is pruned).
+ * Default -28 (3.7e-9); accepted range [-inf, -16] (-inf: nothing is pruned).
  * Process-wide; takes effect for backward calls enqueued afterwards.  A
  * tuning knob without counterpart in the reference (whose dependency computes
  * every element). */

@@ -20,6 +20,7 @@ LAUNCH_FAILURE = 3
 BAD_INPUT_DATA = 4
 FLAG_BAD_LENGTH = 1
 FLAG_BAD_LABEL = 2
+DEFAULT_PRUNE_LOG2 = -28.0  # kPruneLog2 of csrc/workspace.h
 STATIC_WORKSPACE_BYTES = 32 << 20  # RNNT_MI355X_STATIC_WORKSPACE_BYTES
 
 _lib = None

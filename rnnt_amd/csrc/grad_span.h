@@ -56,6 +56,7 @@ __global__ __launch_bounds__(kSpanWaves * 64) void k_grad_span(const float* x, f
   constexpr int RW = NG * R;           // rows per wave
   constexpr int RB = kSpanWaves * RW;  // rows per block
   static_assert(RB <= kSpanMaxRows, "coefficient table");
+  static_assert(RB >= kMinSpanRows, "the workspace holds one partial-sum slot per kMinSpanRows rows");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = lane % L, r = lane / L;
   const int bid = gm.nblocks - 1 - (int)blockIdx.x;  // reverse of the first pass: most recently read rows first
@@ -85,7 +86,12 @@ __global__ __launch_bounds__(kSpanWaves * 64) void k_grad_span(const float* x, f
       const int u = row - t * maxU1;
       float4 cf = make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
       const bool is_cell = i < rows_blk && t < T && u <= U;
+#ifdef RNNT_SPAN_FAKE_PROLOGUE  // timing experiment only (wrong results): no dependent loads before the row loads
+      if (is_cell && u < 44) cf = make_float4(-20.f, 0.f, 0.f, __int_as_float(-1));
+      if (false) {
+#else
       if (is_cell) {
+#endif
         const size_t ci = plane + (size_t)(t + u) * U1s + u;
         const double a_ll = w.alpha[ci] - ll2;
         const float4 rc = w.rec[((size_t)b * (gm.maxT + 2) + 1 + t) * maxU1 + u];  // {lpb, lpl, lse, -}

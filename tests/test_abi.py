@@ -63,13 +63,13 @@ def test_null_and_range_arguments_are_rejected_before_any_launch():
 def test_prune_threshold_setting_and_static_entry_point_validation():
     L = _lib.lib()
     one = ctypes.c_void_p(256)  # never dereferenced: validation fails first
-    assert L.rnnt_mi355x_get_prune_log2() == -40.0
+    assert L.rnnt_mi355x_get_prune_log2() == _lib.DEFAULT_PRUNE_LOG2 == -28.0
     assert L.rnnt_mi355x_set_prune_log2(-8.0) == _lib.INVALID_VALUE       # would show at the 1e-4 bar
     assert L.rnnt_mi355x_set_prune_log2(float("nan")) == _lib.INVALID_VALUE
-    assert L.rnnt_mi355x_set_prune_log2(-28.0) == _lib.OK
-    assert L.rnnt_mi355x_get_prune_log2() == -28.0
+    assert L.rnnt_mi355x_set_prune_log2(-32.0) == _lib.OK
+    assert L.rnnt_mi355x_get_prune_log2() == -32.0
     assert L.rnnt_mi355x_set_prune_log2(float("-inf")) == _lib.OK          # pruning off
-    assert L.rnnt_mi355x_set_prune_log2(-40.0) == _lib.OK
+    assert L.rnnt_mi355x_set_prune_log2(_lib.DEFAULT_PRUNE_LOG2) == _lib.OK
     # the entry point with the built-in workspace rejects what does not fit it, before touching a GPU
     assert _lib.workspace_bytes(8, 150, 41) < _lib.STATIC_WORKSPACE_BYTES < _lib.workspace_bytes(64, 400, 101)
     f = L.rnnt_mi355x_loss_grad_static

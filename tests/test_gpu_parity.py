@@ -98,6 +98,17 @@ SHAPES = [
     (2, 7, 3, 1024, 1023),  # VEC4 L64 nc4 (config 3 vocabulary)
     (2, 4, 2, 4096, 4095),  # VEC4 L64 nc4 x 4 passes (config 4 vocabulary)
     (1, 4, 2, 5000, 77),    # VEC4, chunk count not a multiple of the pass width
+    # the span form of the gradient pass (16-byte aligned rows of 129..4096 logits): every (lanes per row, chunks
+    # per lane) instantiation, row counts that are no multiple of a block's rows, rows shorter than the lanes cover
+    (2, 33, 9, 132, 0),     # span L16: 33 of 64 chunks per row group used
+    (3, 40, 20, 200, 199),  # span L16, ragged, several blocks per utterance
+    (2, 30, 12, 300, 5),    # span L32, 75 of 128 chunks
+    (2, 50, 30, 512, 0),    # span L32 full
+    (2, 37, 11, 1000, 999), # span L64 nc4, masked tail
+    (3, 45, 17, 1024, 7),   # span L64 nc4, ragged
+    (2, 12, 7, 2048, 2047), # span L64 nc8
+    (2, 9, 5, 3000, 1),     # span L64 nc16, masked tail
+    (2, 11, 6, 4096, 17),   # span L64 nc16
     (2, 30, 70, 12, 11),    # sweep K=2
     (2, 20, 150, 8, 0),     # sweep K=4
     (1, 12, 300, 4, 3),     # sweep K=8

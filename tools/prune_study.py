@@ -69,7 +69,7 @@ def main():
                          "step_ms_min": min(ms), "step_ms_median": sorted(ms)[len(ms) // 2],
                          "mean_cost": costs.mean().item()})
             print(json.dumps(rows[-1]), flush=True)
-    L.rnnt_mi355x_set_prune_log2(-40.0)
+    L.rnnt_mi355x_set_prune_log2(_lib.DEFAULT_PRUNE_LOG2)
 
 
 if __name__ == "__main__":

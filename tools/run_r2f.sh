@@ -1,0 +1,15 @@
+mkdir -p gpurun_out/r2f
+timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/r2f/pytest.txt 2>&1; echo "pytest exit $?"; tail -4 gpurun_out/r2f/pytest.txt
+for c in 3 1 2 4 5; do
+  timeout -k 10 400 python -u bench.py --config $c > gpurun_out/r2f/bench_c$c.json 2> gpurun_out/r2f/bench_c$c.err || { echo "bench $c failed"; tail -5 gpurun_out/r2f/bench_c$c.err; exit 1; }
+  python - <<PY
+import json
+j=json.loads(open("gpurun_out/r2f/bench_c$c.json").read().strip().splitlines()[-1])
+k={e["name"]:round(e["ms"],3) for e in j["roofline"]["kernels"]}
+print("config $c: step %.3f ms frac %.3f pruned %.3f" % (j["ms_per_step"], j["roofline"]["frac"], j["pruned_row_frac"]), k, {n:(round(l["ms_per_step"],3), round(l["frac"],3)) for n,l in j.get("legs",{}).items()}, "cpu", round(j["cpu_baseline"]["value"]/1e6,2))
+PY
+done
+timeout -k 10 300 python -u bench.py --config 2 --graph --no-cpu-baseline --no-legs > gpurun_out/r2f/bench_c2_graph.json 2> gpurun_out/r2f/bench_c2_graph.err; echo "graph exit $?"; tail -3 gpurun_out/r2f/bench_c2_graph.err
+python -c "
+import json
+j=json.loads(open('gpurun_out/r2f/bench_c2_graph.json').read().strip().splitlines()[-1]); print('config 2 graph: step %.3f ms frac %.3f' % (j['ms_per_step'], j['roofline']['frac']))"
