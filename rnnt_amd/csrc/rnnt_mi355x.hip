@@ -27,6 +27,7 @@
 // included below:
 //   workspace.h      constants, workspace header and layout
 //   device_util.h    exp2/log2, vector loads, DPP reductions, row cursor
+//   lse_span.h       k_lse_span (aligned rows <= 4096)
 //   lse_rows.h       k_lse                 grad_rows.h   k_grad (any row)   grad_span.h  k_grad_span (aligned rows <= 4096)
 //   sweep.h          k_sweep               small_vocab.h V <= 128 variants of both passes
 //   joint.h          additive joint fused into the loss (matrix-core contractions)
@@ -43,6 +44,7 @@
 #include "sweep.h"
 #include "grad_rows.h"
 #include "grad_span.h"
+#include "lse_span.h"
 #include "small_vocab.h"
 #include "joint.h"
 #include "aux_kernels.h"
@@ -228,6 +230,17 @@ SmallGeom small_geom(const Call& c, int* blocks) {
     }                                                                                                           \
   } while (0)
 
+SpanGeom span_geom(const Call& c, int b0) {
+  SpanGeom sg;
+  sg.maxT = c.maxT; sg.maxU1 = c.maxU1; sg.V = c.V; sg.blank = c.blank;
+  sg.rows_utt = c.maxT * c.maxU1;
+  sg.nchunks = sg.nblocks = sg.nblocks_all = 0;  // set per kernel: they depend on its rows per block
+  sg.b0 = b0;
+  sg.prune_log2 = g_prune_log2.load(std::memory_order_relaxed);
+  sg.xstride = c.xstride; sg.gstride = c.gstride;
+  return sg;
+}
+
 void launch_lse(const Call& c, int b0, int nb, hipStream_t st) {
   if (b0 == 0 && nb == c.B && use_small(c, c.logits)) {
     int blocks;
@@ -238,6 +251,23 @@ void launch_lse(const Call& c, int b0, int nb, hipStream_t st) {
     return;
   }
   const RowCfg cfg = sub_cfg(c, c.logits, b0, nb);
+#ifndef RNNT_NO_LSE_SPAN
+  // (measured: rows of 4 KiB and more gain 2-5 % over k_lse; 2 KiB rows of a ragged batch lose 10 %)
+  if (cfg.vec == 4 && c.V > 512 && c.V <= 4096) {
+    SpanGeom sg = span_geom(c, b0);
+    const int nchunk = c.V / 4;
+    auto go = [&](auto kernel, int rows_per_block) {
+      sg.nchunks = (sg.rows_utt + rows_per_block - 1) / rows_per_block;
+      sg.nblocks = nb * sg.nchunks;
+      sg.nblocks_all = c.B * sg.nchunks;
+      kernel<<<dim3((unsigned)sg.nblocks), dim3(kLseWaves * 64), 0, st>>>(c.logits, c.labels, c.in_len, c.lab_len, sg, c.w);
+    };
+    if (nchunk <= 256) go(k_lse_span<64, 4, RNNT_LSE_NG>, kLseWaves * RNNT_LSE_NG);
+    else if (nchunk <= 512) go(k_lse_span<64, 8, RNNT_LSE_NG / 2>, kLseWaves * (RNNT_LSE_NG / 2));
+    else go(k_lse_span<64, 16, RNNT_LSE_NG / 4>, kLseWaves * (RNNT_LSE_NG / 4));
+    return;
+  }
+#endif
   RNNT_DISPATCH(k_lse, cfg, sizeof(float4) * (size_t)cfg.gm.TT * c.maxU1, c.logits, c.labels, c.in_len, c.lab_len,
                 cfg.gm, c.w);
 }
@@ -273,12 +303,7 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
 #ifndef RNNT_NO_SPAN
   if (cfg.vec == 4 && c.V > 128 && c.V <= 4096) {
     // rows per wave chosen so that a wave owns about 32 KiB: lanes per row L, 16-byte chunks per lane NC, row groups NG
-    SpanGeom sg;
-    sg.maxT = c.maxT; sg.maxU1 = c.maxU1; sg.V = c.V; sg.blank = c.blank;
-    sg.rows_utt = c.maxT * c.maxU1;
-    sg.b0 = b0;
-    sg.prune_log2 = g_prune_log2.load(std::memory_order_relaxed);
-    sg.xstride = c.xstride; sg.gstride = c.gstride;
+    SpanGeom sg = span_geom(c, b0);
     const int nchunk = c.V / 4;
     auto go = [&](auto kernel, int rows_per_block) {
       sg.nchunks = (sg.rows_utt + rows_per_block - 1) / rows_per_block;

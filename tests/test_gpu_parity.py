@@ -128,6 +128,17 @@ def test_shapes_against_oracle(B, T, U, V, blank):
     _check(x, lab, il, ll, blank, gs)
 
 
+@pytest.mark.parametrize("V,blank", [(1024, 1023), (62, 39), (512, 0)])
+def test_very_short_utterance_next_to_a_long_one(V, blank):
+    """Most frames of the short utterance lie far beyond its lattice: the first pass leaves the records of frames
+    the sweeps can never reach unwritten (the workspace is poisoned with NaN here), the gradient pass zero-fills."""
+    B, T, U = 3, 130, 6
+    x, lab, _, _ = make_batch(B, T, U, V, blank, seed=77, ragged=False)
+    il = np.array([T, 9, 40], np.int32)
+    ll = np.array([U, 2, 0], np.int32)
+    _check(x, lab, il, ll, blank)
+
+
 def test_config1_shape():
     """BASELINE config 1: B=8 T=150 U=40 V=62, blank=39."""
     x, lab, il, ll = make_batch(8, 150, 40, 62, 39, seed=0xC0FFEE + 1, ragged=False)
