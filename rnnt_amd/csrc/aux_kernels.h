@@ -66,7 +66,23 @@ __global__ __launch_bounds__(1024) void k_reduce_scalars(const float* __restrict
   const int n = hdr->n_partial;
   double c = 0.0, s = 0.0;
   for (int i = threadIdx.x; i < B; i += 1024) c += (double)costs[i];
-  for (int i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
+  // the partials as float4 (the array starts on a 256-byte boundary), four loads in flight per thread: the loop is
+  // latency-bound, not bandwidth-bound (tens of thousands of entries at most)
+  const float4* p4 = reinterpret_cast<const float4*>(partial);
+  const int n4 = n >> 2;
+  int i = threadIdx.x;
+  for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+    const float4 a = p4[i], b4 = p4[i + 1024], c4 = p4[i + 2048], d4 = p4[i + 3072];
+    s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+    s += ((double)b4.x + (double)b4.y) + ((double)b4.z + (double)b4.w);
+    s += ((double)c4.x + (double)c4.y) + ((double)c4.z + (double)c4.w);
+    s += ((double)d4.x + (double)d4.y) + ((double)d4.z + (double)d4.w);
+  }
+  for (; i < n4; i += 1024) {
+    const float4 a = p4[i];
+    s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+  }
+  for (int k = (n4 << 2) + threadIdx.x; k < n; k += 1024) s += (double)partial[k];
   sh[0][threadIdx.x] = c;
   sh[1][threadIdx.x] = s;
   __syncthreads();

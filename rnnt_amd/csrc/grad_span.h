@@ -85,27 +85,36 @@ __global__ __launch_bounds__(kSpanWaves * 64) void k_grad_span(const float* x, f
       const int t = row / maxU1;
       const int u = row - t * maxU1;
       float4 cf = make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
-      const bool is_cell = i < rows_blk && t < T && u <= U;
+      const bool in_tensor = i < rows_blk;
+      const bool is_cell = in_tensor && t < T && u <= U;
 #ifdef RNNT_SPAN_FAKE_PROLOGUE  // timing experiment only (wrong results): no dependent loads before the row loads
       if (is_cell && u < 44) cf = make_float4(-20.f, 0.f, 0.f, __int_as_float(-1));
       if (false) {
 #else
-      if (is_cell) {
+      if (in_tensor) {
 #endif
+        // Everything a cell needs is requested at once, for every row of the tensor and before the utterance's
+        // lengths are looked at (addresses clamped into the arrays; what is loaded for a row without a cell is not
+        // used): one round trip to memory instead of three dependent ones ahead of the block's row loads.
         const size_t ci = plane + (size_t)(t + u) * U1s + u;
-        const double a_ll = w.alpha[ci] - ll2;
+        const size_t ci_t = (t + u + 1 < w.D) ? ci + U1s : ci;
+        const size_t ci_u = (u + 1 < U1s) ? ci_t + 1 : ci_t;
+        const double al = w.alpha[ci], be = w.beta[ci], be_t = w.beta[ci_t], be_u = w.beta[ci_u];
         const float4 rc = w.rec[((size_t)b * (gm.maxT + 2) + 1 + t) * maxU1 + u];  // {lpb, lpl, lse, -}
-        const float g2 = (float)(a_ll + w.beta[ci]);                               // log2 gamma
-        if (g2 >= gm.prune_log2) {
+        int lab = 0;
+        if (maxU1 > 1) lab = labels[(size_t)b * (maxU1 - 1) + min(u, maxU1 - 2)];
+        const double a_ll = al - ll2;
+        const float g2 = (float)(a_ll + be);  // log2 gamma
+        if (is_cell && g2 >= gm.prune_log2) {
           float e_b = -INFINITY;  // 2^-inf = 0: no blank move out of this cell
-          if (t < T - 1) e_b = (float)(a_ll + w.beta[ci + U1s]) + rc.x;
+          if (t < T - 1) e_b = (float)(a_ll + be_t) + rc.x;
           else if (u == U) e_b = (float)a_ll + rc.x;
           float plv = 0.f;
-          int lab = -1;
           if (u < U) {
-            lab = labels[(size_t)b * (maxU1 - 1) + u];
             lab = (lab < 0 || lab >= V) ? 0 : lab;
-            plv = fast_exp2((float)(a_ll + w.beta[ci + U1s + 1]) + rc.y);
+            plv = fast_exp2((float)(a_ll + be_u) + rc.y);
+          } else {
+            lab = -1;
           }
           cf = make_float4(g2 - rc.z, fast_exp2(e_b), plv, __int_as_float(lab));
         }
