@@ -195,8 +195,9 @@ def parse_args(argv=None):
     ap.add_argument("--partition", default="auto", help="cells | bucketed | greedy | auto (rnnt_amd.sharding.partition)")
     ap.add_argument("--prune-log2", type=float, default=None, help="pruning threshold of the gradient pass (library default -28)")
     ap.add_argument("--logit-scale", type=float, default=1.0, help="logits ~ N(0,1) * scale")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay each step from a captured HIP graph (kernel times then come from a separate instrumented pass)")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto", nargs="?", const="on",
+                    help="replay each step from a captured HIP graph (kernel times then come from a separate instrumented "
+                         "pass).  auto: on for multi-rank runs, whose per-rank steps are short and launch-bound")
     return ap.parse_args(argv)
 
 
@@ -216,6 +217,8 @@ def run_rank(args) -> None:
 
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    force_pg = bool(os.environ.get("BENCH_FORCE_PROCESS_GROUP"))  # rehearsal of the N > 1 code path with one rank
+    args.graph = args.graph == "on" or (args.graph == "auto" and (world > 1 or force_pg))
     n_dev = torch.cuda.device_count()  # does not initialise the GPU
     if n_dev < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -227,13 +230,15 @@ def run_rank(args) -> None:
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or force_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "gloo":  # single-node rehearsal: the host name may not resolve
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group(args.backend, rank=rank, world_size=world,
                                 **({"device_id": dev} if args.backend == "nccl" else {}))
         world = dist.get_world_size()  # the ranks that actually joined
+    multi = world > 1 or force_pg
     on_device_comm = args.backend == "nccl"
     comm_dev = dev if on_device_comm else torch.device("cpu")
     dbg("process group ready")
@@ -343,7 +348,7 @@ def run_rank(args) -> None:
             ev_kernels.append(ev)
         else:
             launch(i)
-        if world > 1:
+        if multi:
             if on_device_comm:  # RCCL, enqueued behind the step; awaited before the segment's closing barrier
                 pending.append(dist.all_reduce(scal[i], async_op=True))
             else:  # gloo rehearsal: reduce a host copy
@@ -358,7 +363,7 @@ def run_rank(args) -> None:
             w.wait()
         pending.clear()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(bar)
             torch.cuda.synchronize(dev)
 
@@ -382,11 +387,19 @@ def run_rank(args) -> None:
         refill()
         launch(0)  # load the kernels outside the capture
         torch.cuda.synchronize(dev)
-        for i in range(ring_n):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                launch(i, on=torch.cuda.current_stream(dev))
-            graphs[i] = g
+        try:
+            for i in range(ring_n):
+                g = torch.cuda.CUDAGraph()
+                # thread-local: other threads of this process (the collective library's watchdog) may go on making
+                # HIP calls while this thread captures
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    launch(i, on=torch.cuda.current_stream(dev))
+                graphs[i] = g
+        except Exception as e:  # no graph: run the steps eagerly
+            print(f"bench.py: HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graphs.clear()
+            args.graph = False
+            torch.cuda.synchronize(dev)
     run_steps(args.warmup, False)
     dbg("warmup done")
     elapsed_local = run_steps(args.steps, True)
@@ -394,7 +407,7 @@ def run_rank(args) -> None:
 
     def reduce_max(v):
         t = torch.tensor([v], dtype=torch.float64, device=comm_dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -534,7 +547,7 @@ def run_rank(args) -> None:
         out["legs"] = legs
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
