@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 
+from . import build as _build
 from .build import LIB as _DEFAULT_LIB
 
 # RNNT_MI355X_LIB selects another build of the same library (debug / experiment builds).
@@ -76,6 +77,14 @@ def lib() -> ctypes.CDLL:
             raise RNNTLibraryError(
                 f"{LIB} is missing: build it with `python -m rnnt_amd.build` (needs hipcc); "
                 "rnnt_amd has no CPU or eager fallback")
+        if LIB == _DEFAULT_LIB and _build.needs_build():
+            # a source is newer than the binary: rebuild where a compiler is at hand, never run the stale one silently
+            try:
+                _build.hipcc_path()
+            except RuntimeError:
+                raise RNNTLibraryError(f"{LIB} is older than its sources ({_build.newer_sources()}) and hipcc is not "
+                                       "available to rebuild it") from None
+            _build.build()
         try:
             handle = ctypes.CDLL(LIB)
         except OSError as e:

@@ -34,6 +34,14 @@ def needs_build() -> bool:
     return any(os.path.getmtime(p) > t for p in (*SOURCES, *PIECES, HEADER))
 
 
+def newer_sources():
+    """Sources that are newer than the built library."""
+    if not os.path.exists(LIB):
+        return [*SOURCES]
+    t = os.path.getmtime(LIB)
+    return [p for p in (*SOURCES, *PIECES, HEADER) if os.path.getmtime(p) > t]
+
+
 def build(force: bool = False, verbose: bool = False, defines=(), out: str = LIB) -> str:
     """defines / out: experiment builds (`-DNAME=VALUE` variants of the library under another file name, selected
     at run time with RNNT_MI355X_LIB)."""

@@ -125,15 +125,17 @@ class _RNNTLossFn(torch.autograd.Function):
             _lib.check(rc, "rnnt_mi355x_forward")
             if check_inputs:
                 _raise_on_flags(ws, dev)
-        ctx.acts, ctx.labels, ctx.il, ctx.ll, ctx.ws = acts_full, labels, il, ll, ws
+        # saved through autograd, so that an in-place edit of acts between forward and backward is detected
+        ctx.save_for_backward(acts_full, labels, il, ll)
+        ctx.ws = ws
         ctx.blank, ctx.inplace, ctx.t_offset = blank, inplace, t_offset
         return costs
 
     @staticmethod
     def backward(ctx, grad_costs):
-        acts_full = ctx.acts
-        if acts_full is None:
+        if ctx.ws is None:
             raise RuntimeError("rnnt_loss: backward called twice (the lattice state was released)")
+        acts_full, labels, il, ll = ctx.saved_tensors
         B, T0, U1, V = acts_full.shape
         t_offset = ctx.t_offset
         T = T0 - t_offset
@@ -142,20 +144,24 @@ class _RNNTLossFn(torch.autograd.Function):
             scale = grad_costs.to(device=dev, dtype=torch.float32).reshape(B).contiguous()
             grad_full = acts_full if ctx.inplace else torch.empty(acts_full.shape, dtype=torch.float32, device=dev)
             if acts_full.is_contiguous():  # the library zero-fills the cropped frames itself
-                rc = _lib.lib().rnnt_mi355x_backward_cropped(_ptr(acts_full), _ptr(grad_full), _ptr(ctx.labels),
-                                                             _ptr(ctx.il), _ptr(ctx.ll), B, T0, t_offset, U1, V, ctx.blank,
+                rc = _lib.lib().rnnt_mi355x_backward_cropped(_ptr(acts_full), _ptr(grad_full), _ptr(labels),
+                                                             _ptr(il), _ptr(ll), B, T0, t_offset, U1, V, ctx.blank,
                                                              _ptr(scale), _ptr(ctx.ws), _stream_ptr(dev))
             else:
                 view, gview = acts_full[:, t_offset:], grad_full[:, t_offset:]
                 xs = view.stride(0) if B > 1 else T * U1 * V
                 gs = gview.stride(0) if B > 1 else T * U1 * V
-                rc = _lib.lib().rnnt_mi355x_backward_strided(_ptr(view), xs, _ptr(gview), gs, _ptr(ctx.labels),
-                                                             _ptr(ctx.il), _ptr(ctx.ll), B, T, U1, V, ctx.blank,
+                rc = _lib.lib().rnnt_mi355x_backward_strided(_ptr(view), xs, _ptr(gview), gs, _ptr(labels),
+                                                             _ptr(il), _ptr(ll), B, T, U1, V, ctx.blank,
                                                              _ptr(scale), _ptr(ctx.ws), _stream_ptr(dev))
                 if t_offset:
                     grad_full[:, :t_offset].zero_()  # the cropped frames take no part in the loss
             _lib.check(rc, "rnnt_mi355x_backward")
-        ctx.acts = ctx.ws = None
+            if ctx.inplace:
+                # the kernel wrote through a raw pointer: tell autograd, so that whoever else saved this tensor for
+                # its own backward (the op that produced it) gets an error instead of the gradient's bytes
+                torch.autograd.graph.increment_version(acts_full)
+        ctx.ws = None
         return grad_full, None, None, None, None, None, None, None
 
 
@@ -174,7 +180,9 @@ def rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0, *, inpl
     frames of that crop) without copying: the reference's ``shift = 2`` crop
     (util.py:62-64).  The gradient of the skipped frames is zero.
     inplace=True lets backward overwrite ``acts`` with its gradient (saves a
-    [B,T,U+1,V] allocation); only legal when nothing else reads ``acts`` later.
+    [B,T,U+1,V] allocation); only legal when nothing else reads ``acts`` later:
+    the overwrite is reported to autograd, so an op that saved ``acts`` for its
+    own backward (a tanh that produced it) raises instead of using the gradient.
     check_inputs=True raises ValueError on malformed lengths/labels: lengths
     and labels given as host tensors are checked on the host; otherwise a 4-byte
     validation word is read back after the forward (one stream sync).
@@ -211,15 +219,17 @@ class _RNNTJointLossFn(torch.autograd.Function):
             _lib.check(rc, "rnnt_mi355x_joint_forward")
             if check_inputs:
                 _raise_on_flags(ws, dev)
-        ctx.saved = (f_full, g, labels, il, ll, ws)
+        ctx.save_for_backward(f_full, g, labels, il, ll)
+        ctx.ws = ws
         ctx.blank, ctx.t_offset = blank, t_offset
         return costs
 
     @staticmethod
     def backward(ctx, grad_costs):
-        if ctx.saved is None:
+        if ctx.ws is None:
             raise RuntimeError("rnnt_joint_loss: backward called twice (the lattice state was released)")
-        f_full, g, labels, il, ll, ws = ctx.saved
+        f_full, g, labels, il, ll = ctx.saved_tensors
+        ws = ctx.ws
         B, T0, V = f_full.shape
         U1 = g.shape[1]
         t_offset = ctx.t_offset
@@ -238,7 +248,7 @@ class _RNNTJointLossFn(torch.autograd.Function):
             _lib.check(rc, "rnnt_mi355x_joint_backward")
             if t_offset:
                 df_full[:, :t_offset].zero_()
-        ctx.saved = None
+        ctx.ws = None
         return df_full, dg, None, None, None, None, None, None
 
 

@@ -89,6 +89,35 @@ def test_inplace_backward_reuses_the_acts_buffer():
     assert acts.data_ptr() == ptr and np.abs(acts.detach().cpu().numpy() - go).max() < GRAD_ATOL
 
 
+def test_inplace_backward_is_reported_to_autograd():
+    """inplace=True overwrites acts through a raw pointer; an op that saved acts for its own backward (tanh saves
+    its output) must then get autograd's in-place error, not the gradient's bytes; so must an edit of acts between
+    forward and backward, and a second backward."""
+    x, lab, il, ll = make_batch(2, 9, 4, 32, 31, seed=14)
+    base = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    acts = torch.tanh(base)
+    costs = rnnt_amd.rnnt_loss(acts, lab, il, ll, 31, inplace=True)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        costs.sum().backward()
+    # the same model with inplace=False is fine
+    base2 = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    rnnt_amd.rnnt_loss(torch.tanh(base2), lab, il, ll, 31).sum().backward()
+    _, go = orc.rnnt_loss_and_grad(np.tanh(x.astype(np.float64)), lab, il, ll, 31)
+    assert np.abs(base2.grad.cpu().numpy() - go * (1 - np.tanh(x.astype(np.float64)) ** 2)).max() < GRAD_ATOL
+    # acts edited between forward and backward
+    acts3 = (torch.from_numpy(x).to(DEV).requires_grad_(True)) * 1.0
+    c3 = rnnt_amd.rnnt_loss(acts3, lab, il, ll, 31)
+    acts3.mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        c3.sum().backward()
+    # second backward
+    acts4 = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    c4 = rnnt_amd.rnnt_loss(acts4, lab, il, ll, 31)
+    c4.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="twice"):
+        c4.sum().backward()
+
+
 def test_fused_inplace_call_and_scalars():
     x, lab, il, ll = make_batch(3, 12, 6, 48, 0, seed=13)
     acts = torch.from_numpy(x).to(DEV)
