@@ -321,6 +321,7 @@ def run_rank(args) -> None:
         e.record(stream)  # materialises the hipEvent_t; the library re-records it
         return e
 
+    ev_grad = []     # per timed step: (before, after) the gradient pass, the dominant kernel
     ev_kernels = []  # per instrumented step: (before lse, after lse, after sweep, after grad, after scalars)
     pending = []     # all-reduce handles of the current segment
 
@@ -329,7 +330,7 @@ def run_rank(args) -> None:
         s = sp if on is None else ctypes.c_void_p(on.cuda_stream)
         arr = None
         if events is not None:
-            arr = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(e.cuda_event) for e in events[:4]])
+            arr = (ctypes.c_void_p * 4)(*[None if e is None else ctypes.c_void_p(e.cuda_event) for e in events[:4]])
         rc = L.rnnt_mi355x_loss_grad_events(_p(ring[i]), _p(labels), _p(il), _p(ll), *meta, _p(grad_scale), _p(costs),
                                             _p(ws), s, arr)
         rc |= L.rnnt_mi355x_reduce_scalars(_p(costs), B, _p(ws), _p(scal[i]), s)
@@ -339,13 +340,20 @@ def run_rank(args) -> None:
     graphs = {}
 
     def step(i, timed):
-        if args.graph:
+        """timed: False = no events; True = two events around the gradient pass (the timed region: every event
+        costs a few microseconds of stream time, so only the dominant kernel is bracketed there); "all" = events
+        around every kernel (the instrumented pass after the timed region)."""
+        if args.graph and timed != "all":
             graphs[i].replay()
-        elif timed:
+        elif timed == "all":
             ev = [new_event() for _ in range(4)]
             launch(i, ev)
             ev.append(new_event())
             ev_kernels.append(ev)
+        elif timed:
+            ev = [None, None, new_event(), new_event()]
+            launch(i, ev)
+            ev_grad.append((ev[2], ev[3]))
         else:
             launch(i)
         if multi:
@@ -433,10 +441,7 @@ def run_rank(args) -> None:
     if n_cells_seen != cells:
         raise RuntimeError(f"the gradient pass visited {n_cells_seen} lattice cells, expected {cells}")
 
-    if args.graph:  # kernel times from an instrumented pass outside the timed region
-        args.graph = False
-        run_steps(min(ring_n, 5), True)
-        args.graph = True
+    run_steps(min(ring_n, 6), "all")  # instrumented pass outside the timed region: every kernel bracketed
 
     ms_per_step = elapsed / args.steps * 1e3
     value = total_cells * args.steps / elapsed
@@ -445,6 +450,8 @@ def run_rank(args) -> None:
     kt = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(4)] for e in ev_kernels])  # lse, sweep, grad, scalars
     step_dev = np.array([e[0].elapsed_time(e[4]) for e in ev_kernels])
     k_ms = kt.mean(axis=0)
+    if ev_grad:  # the dominant kernel's time comes from the timed region itself
+        k_ms[2] = float(np.mean([a.elapsed_time(b) for a, b in ev_grad]))
     pruned_frac = n_pruned / max(cells, 1)
 
     counter = {}
@@ -518,8 +525,10 @@ def run_rank(args) -> None:
             "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this "
                                "workload; not measured in this run)" if counter else None),
             "dominant_kernel": dominant["name"],
-            "kernel_times_from": ("HIP events on the launch stream inside the timed region" if not args.graph else
-                                  "HIP events in a separate instrumented pass (the timed region replays graphs)"),
+            "kernel_times_from": ("k_grad: HIP events on the launch stream around every launch of the timed region; k_lse, "
+                                  "k_sweep and step_ms_device: an instrumented pass of %d steps right after it"
+                                  % min(ring_n, 6) if not args.graph else
+                                  "HIP events in an instrumented pass right after the timed region (which replays graphs)"),
             "kernels": kernels,
         },
     }
