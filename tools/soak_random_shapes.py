@@ -9,6 +9,10 @@ if len(sys.argv) > 3:
 only = os.environ.get("SOAK_ONLY", "").split(",") if os.environ.get("SOAK_ONLY") else None  # e.g. SOAK_ONLY=dense,decode
 if os.environ.get("SOAK_BIG"):  # lattices up to 600 frames x 1024 label positions, ten times the cells
     t.MAX_T, t.MAX_U1, t.SIZE_FACTOR = 600, 1024, 10
+if os.environ.get("SOAK_VMAX"):  # vocabularies up to this size (default 1200), e.g. 4500 for the widest row kernels
+    d = list(t._draw.__defaults__)
+    d[2] = int(os.environ["SOAK_VMAX"])
+    t._draw.__defaults__ = tuple(d)
 bad = 0
 for name, fn, lo in (("abi", t.test_random_logits_through_the_c_abi, first), ("crop", t.test_random_crops_along_t, first + 100000),
                      ("joint", t.test_random_additive_joints, first + 200000), ("dense", t.test_random_dense_layers, first + 300000),
