@@ -44,6 +44,7 @@
 #include "sweep.h"
 #include "grad_rows.h"
 #include "grad_span.h"
+#include "grad_flat.h"
 #include "lse_span.h"
 #include "small_vocab.h"
 #include "joint.h"
@@ -300,6 +301,28 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
     k_zero_frames<<<dim3(per_b, (unsigned)c.B), 256, 0, st>>>(c.grad - n, c.gstride, n);
   }
   const RowCfg cfg = sub_cfg(c, c.grad, b0, nb);
+  // Rows that are a whole number of 512-byte pieces go to k_grad_span (lanes tied to rows), every other aligned row
+  // of 32..4096 logits to k_grad_flat (lanes tied to memory).  Measured at B=64, T=500, U=100 (bytes read + written
+  // per second, flattered alike by pruned rows; span / flat): V=132 5.6 / 8.2, 160 7.3 / 8.3, 200 5.6 / 8.3,
+  // 300 6.6 / 8.0 against V=256 8.5 / 8.3, 512 9.1 / 8.2, 1024 9.3 / 8.1 TB/s.
+#ifndef RNNT_NO_FLAT
+  if (cfg.vec == 4 && c.V >= 32 && c.V <= 4096 && (c.V % 128 != 0 || c.V <= 128)) {
+    FlatGeom fg;
+    fg.maxT = c.maxT; fg.maxU1 = c.maxU1; fg.V = c.V; fg.blank = c.blank;
+    fg.rows_utt = c.maxT * c.maxU1;
+    fg.nchunk = c.V / 4;
+    fg.q64 = 64 / fg.nchunk; fg.r64 = 64 % fg.nchunk;
+    const long long total = (long long)fg.rows_utt * fg.nchunk;
+    fg.blocks_utt = (int)((total + kFlatChunksPerBlock - 1) / kFlatChunksPerBlock);
+    fg.table_rows = kFlatChunksPerBlock / fg.nchunk + 2;
+    fg.b0 = b0; fg.nblocks = nb * fg.blocks_utt; fg.nblocks_all = c.B * fg.blocks_utt;
+    fg.prune_log2 = g_prune_log2.load(std::memory_order_relaxed);
+    fg.xstride = c.xstride; fg.gstride = c.gstride;
+    k_grad_flat<<<dim3((unsigned)fg.nblocks), dim3(kFlatWaves * 64), sizeof(float4) * (size_t)fg.table_rows, st>>>(
+        c.logits, c.grad, c.labels, c.in_len, c.lab_len, c.grad_scale, fg, c.w);
+    return;
+  }
+#endif
 #ifndef RNNT_NO_SPAN
   if (cfg.vec == 4 && c.V > 128 && c.V <= 4096) {
     // rows per wave chosen so that a wave owns about 32 KiB: lanes per row L, 16-byte chunks per lane NC, row groups NG

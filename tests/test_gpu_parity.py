@@ -98,17 +98,26 @@ SHAPES = [
     (2, 7, 3, 1024, 1023),  # VEC4 L64 nc4 (config 3 vocabulary)
     (2, 4, 2, 4096, 4095),  # VEC4 L64 nc4 x 4 passes (config 4 vocabulary)
     (1, 4, 2, 5000, 77),    # VEC4, chunk count not a multiple of the pass width
-    # the span form of the gradient pass (16-byte aligned rows of 129..4096 logits): every (lanes per row, chunks
-    # per lane) instantiation, row counts that are no multiple of a block's rows, rows shorter than the lanes cover
-    (2, 33, 9, 132, 0),     # span L16: 33 of 64 chunks per row group used
-    (3, 40, 20, 200, 199),  # span L16, ragged, several blocks per utterance
-    (2, 30, 12, 300, 5),    # span L32, 75 of 128 chunks
+    # the span forms of the two passes (rows that are whole multiples of 512 bytes, up to 4096 logits): every
+    # (lanes per row, chunks per lane) instantiation, row counts that are no multiple of a block's rows
+    (2, 33, 9, 256, 0),     # span L16
+    (2, 20, 9, 384, 3),     # span L32, 96 of 128 chunks
     (2, 50, 30, 512, 0),    # span L32 full
-    (2, 37, 11, 1000, 999), # span L64 nc4, masked tail
+    (3, 45, 17, 768, 767),  # span L64 nc4, 192 of 256 chunks, ragged
     (3, 45, 17, 1024, 7),   # span L64 nc4, ragged
     (2, 12, 7, 2048, 2047), # span L64 nc8
-    (2, 9, 5, 3000, 1),     # span L64 nc16, masked tail
+    (2, 9, 5, 3072, 1),     # span L64 nc16, 768 of 1024 chunks
     (2, 11, 6, 4096, 17),   # span L64 nc16
+    # the flat form of the gradient pass (any other 16-byte aligned row of 32..4096 logits): rows that straddle
+    # waves and blocks, blocks that hold hundreds of short rows, several blocks per utterance
+    (2, 33, 9, 132, 0),
+    (3, 40, 20, 200, 199),
+    (2, 30, 12, 300, 5),
+    (2, 37, 11, 1000, 999),
+    (2, 9, 5, 3000, 1),
+    (1, 4, 2, 4092, 4091),
+    (2, 70, 50, 36, 35),    # 144-byte rows: 1366 rows per block
+    (3, 160, 90, 100, 99),  # 400-byte rows, three blocks per utterance, ragged
     (2, 30, 70, 12, 11),    # sweep K=2
     (2, 20, 150, 8, 0),     # sweep K=4
     (1, 12, 300, 4, 3),     # sweep K=8
@@ -247,7 +256,7 @@ def test_unaligned_base_pointer_falls_back_to_narrower_loads():
         assert np.abs(view.cpu().numpy() - go).max() < GRAD_ATOL_TIGHT
 
 
-@pytest.mark.parametrize("V,blank", [(1024, 1023), (62, 39), (40, 39)])
+@pytest.mark.parametrize("V,blank", [(1024, 1023), (62, 39), (40, 39), (100, 7), (300, 299)])
 def test_batch_strided_entry_points(V, blank):
     """rnnt_mi355x_forward_strided / backward_strided on a crop along T of a larger
     tensor (utterances T0*U1*V elements apart), in place and out of place."""
