@@ -1,5 +1,6 @@
-// Part of the single translation unit rnnt_mi355x.hip: k_grad_flat, the gradient pass for 16-byte aligned rows of
-// 32 to 4096 logits of any length (no row needs to be a whole number of cache lines).
+// Part of the single translation unit rnnt_mi355x.hip: k_grad_flat, the gradient pass for utterances that start on
+// 16-byte boundaries, with rows of 32 to 4096 logits of any length (no row needs to be a whole number of cache
+// lines, or even of 16-byte pieces).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -17,7 +18,8 @@ namespace {
 // owns kFlatWaves * 32 KiB of it, every wave a contiguous 32 KiB, every load / store instruction of a wave one
 // contiguous KiB whatever V is (rows of 800 or 1200 bytes straddle cache lines when lanes are tied to rows).
 // Each chunk looks up the {c2, pb, pl, label} of its row in the block's LDS table; (row, column) of a lane's
-// chunks advance incrementally, without divisions.
+// chunks advance incrementally, without divisions.  When V is no multiple of 4 (the reference's 62-symbol
+// vocabulary: 248-byte rows) a chunk may hold the end of one row and the start of the next: it then looks both up.
 // ---------------------------------------------------------------------------
 #ifndef RNNT_FLAT_WAVES
 #define RNNT_FLAT_WAVES 6
@@ -29,15 +31,15 @@ constexpr int kFlatChunksPerBlock = kFlatWaves * 64 * kFlatNch;
 struct FlatGeom {
   int maxT, maxU1, V, blank;
   int rows_utt;         // maxT * maxU1
-  int nchunk;           // V / 4
-  int q64, r64;         // 64 / nchunk, 64 % nchunk
+  int q256, r256;       // 256 / V, 256 % V: how (row, column) move from one chunk of a lane to its next
   int blocks_utt;       // blocks per utterance
-  int table_rows;       // rows of the LDS coefficient table = kFlatChunksPerBlock / nchunk + 2
+  int table_rows;       // rows of the LDS coefficient table = 4 * kFlatChunksPerBlock / V + 2
   int b0, nblocks, nblocks_all;
   float prune_log2;
   size_t xstride, gstride;
 };
 
+template <bool ROWS4>  // V % 4 == 0: no chunk straddles two rows
 __global__ __launch_bounds__(kFlatWaves * 64) __attribute__((amdgpu_waves_per_eu(3))) void k_grad_flat(const float* x, float* grad,
                                                               const int32_t* __restrict__ labels,
                                                               const int32_t* __restrict__ in_len,
@@ -51,15 +53,15 @@ __global__ __launch_bounds__(kFlatWaves * 64) __attribute__((amdgpu_waves_per_eu
   const int bl = bid / gm.blocks_utt;
   const int b = gm.b0 + bl;
   const int kblk = bid - bl * gm.blocks_utt;
-  const int V = gm.V, blank = gm.blank, maxU1 = gm.maxU1, nchunk = gm.nchunk;
-  const long long g0 = (long long)kblk * kFlatChunksPerBlock;      // first chunk of this block in the utterance
-  const long long total = (long long)gm.rows_utt * nchunk;         // chunks of the utterance
-  const int row_first = (int)(g0 / nchunk);
-  const int rem0 = (int)(g0 - (long long)row_first * nchunk);      // the block starts this far into row_first
-  const long long gend = min(g0 + kFlatChunksPerBlock, total);
-  const int nrows = (int)((gend - 1) / nchunk) + 1 - row_first;    // rows this block touches
-  const float* xblk = x + (size_t)b * gm.xstride + (size_t)g0 * 4;
-  float* gblk = grad + (size_t)b * gm.gstride + (size_t)g0 * 4;
+  const int V = gm.V, blank = gm.blank, maxU1 = gm.maxU1;
+  const long long g0 = (long long)kblk * (4 * kFlatChunksPerBlock);  // first element of this block in the utterance
+  const long long total = (long long)gm.rows_utt * V;                // elements of the utterance
+  const int row_first = (int)(g0 / V);
+  const int rem0 = (int)(g0 - (long long)row_first * V);             // the block starts this far into row_first
+  const long long gend = min(g0 + 4 * kFlatChunksPerBlock, total);
+  const int nrows = (int)((gend - 1) / V) + 1 - row_first;           // rows this block touches
+  const float* xblk = x + (size_t)b * gm.xstride + (size_t)g0;
+  float* gblk = grad + (size_t)b * gm.gstride + (size_t)g0;
   const float sc = grad_scale ? grad_scale[b] : 1.f;
   int T, U;
   utt_dims(in_len, lab_len, b, gm.maxT, maxU1, T, U);
@@ -121,12 +123,13 @@ __global__ __launch_bounds__(kFlatWaves * 64) __attribute__((amdgpu_waves_per_eu
     w.pcount[gm.b0 * gm.blocks_utt + bid] = c;
   }
 
-  // this lane's first chunk: f0 chunks into the block, i.e. (row_l0, col0) in the table's rows
+  // this lane's first chunk: f0 chunks into the block, its first element at (row_l0, col0) in the table's rows
   const int f0 = wv * CPW + lane;
-  const int pos0 = rem0 + f0;
-  const int row_l0 = pos0 / nchunk;
-  const int col0 = pos0 - row_l0 * nchunk;
-  const int left = (int)(gend - g0);  // chunks of this block inside the utterance
+  const int pos0 = rem0 + 4 * f0;
+  const int row_l0 = pos0 / V;
+  const int col0 = pos0 - row_l0 * V;
+  const int left_e = (int)(gend - g0);  // elements of this block inside the utterance
+  const int left = left_e >> 2;         // whole chunks (an utterance's last chunk may be partial: handled at the end)
   // a wave's chunk i sits at (scalar base of the wave) + i KiB + 16 * lane: one 32-bit vector offset for all 32
   const char* xw = reinterpret_cast<const char*>(xblk + (size_t)wv * CPW * 4);
   char* gw = reinterpret_cast<char*>(gblk + (size_t)wv * CPW * 4);
@@ -139,16 +142,17 @@ __global__ __launch_bounds__(kFlatWaves * 64) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int f = f0 + 64 * i;
-      const bool active = f < left && coef_s[f < left ? row_l : 0].x > -INFINITY;
+      bool active = f < left && coef_s[f < left ? row_l : 0].x > -INFINITY;
+      if (!ROWS4) active = active || (f < left && col + 3 >= V && coef_s[row_l + 1].x > -INFINITY);
       if (active) {
         load_vec<4>(reinterpret_cast<const float*>(xw + 1024 * i + voff), v[i]);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[i][q] = 0.f;
       }
-      row_l += gm.q64;
-      col += gm.r64;
-      if (col >= nchunk) { col -= nchunk; ++row_l; }
+      row_l += gm.q256;
+      col += gm.r256;
+      if (col >= V) { col -= V; ++row_l; }
       // keep the table look-ups next to their loads (hoisting all 32 of them costs registers the rows need)
       if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
@@ -167,31 +171,68 @@ __global__ __launch_bounds__(kFlatWaves * 64) __attribute__((amdgpu_waves_per_eu
       const int f = f0 + 64 * i;
       if (f < left) {
         const float4 cf = coef_s[row_l];
-        const float c2 = cf.x, pb = cf.y, pl = cf.z;
-        const int lab = __float_as_int(cf.w);
         float o[4];
-        if (c2 > -INFINITY) {
+        if (ROWS4 || col + 3 < V) {  // the whole chunk lies in one row
+          const float c2 = cf.x, pb = cf.y, pl = cf.z;
+          const int lab = __float_as_int(cf.w);
+          if (c2 > -INFINITY) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int e = col + q;
+              float gv = fast_exp2(__builtin_fmaf(v[i][q], kLog2e, c2));
+              gv -= (e == blank) ? pb : 0.f;
+              gv -= (e == lab) ? pl : 0.f;
+              gv *= sc;
+              sqsum = __builtin_fmaf(gv, gv, sqsum);
+              o[q] = gv;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = 0.f;
+          }
+        } else {  // the end of one row and the start of the next
+          const float4 cn = coef_s[row_l + 1];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int e = col * 4 + q;
-            float gv = fast_exp2(__builtin_fmaf(v[i][q], kLog2e, c2));
-            gv -= (e == blank) ? pb : 0.f;
-            gv -= (e == lab) ? pl : 0.f;
-            gv *= sc;
-            sqsum = __builtin_fmaf(gv, gv, sqsum);
+            const bool nxt = col + q >= V;
+            const int e = nxt ? col + q - V : col + q;
+            const float c2 = nxt ? cn.x : cf.x, pb = nxt ? cn.y : cf.y, pl = nxt ? cn.z : cf.z;
+            const int lab = __float_as_int(nxt ? cn.w : cf.w);
+            float gv = 0.f;
+            if (c2 > -INFINITY) {
+              gv = fast_exp2(__builtin_fmaf(v[i][q], kLog2e, c2));
+              gv -= (e == blank) ? pb : 0.f;
+              gv -= (e == lab) ? pl : 0.f;
+              gv *= sc;
+              sqsum = __builtin_fmaf(gv, gv, sqsum);
+            }
             o[q] = gv;
           }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = 0.f;
         }
         store_vec<4>(reinterpret_cast<float*>(gw + 1024 * i + voff), o);
       }
-      row_l += gm.q64;
-      col += gm.r64;
-      if (col >= nchunk) { col -= nchunk; ++row_l; }
+      row_l += gm.q256;
+      col += gm.r256;
+      if (col >= V) { col -= V; ++row_l; }
       if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+  }
+
+  // the utterance's last, partial chunk (its element count is no multiple of 4): element by element
+  if (!ROWS4 && (left_e & 3) && threadIdx.x < (left_e & 3)) {
+    const int off = (left << 2) + threadIdx.x;  // element offset inside the block
+    const int pos = rem0 + off;
+    const int rl = pos / V, e = pos - rl * V;
+    const float4 cf = coef_s[rl];
+    float gv = 0.f;
+    if (cf.x > -INFINITY) {
+      gv = fast_exp2(__builtin_fmaf(xblk[off], kLog2e, cf.x));
+      gv -= (e == blank) ? cf.y : 0.f;
+      gv -= (e == __float_as_int(cf.w)) ? cf.z : 0.f;
+      gv *= sc;
+      sqsum = __builtin_fmaf(gv, gv, sqsum);
+    }
+    gblk[off] = gv;
   }
 
   // per-block sum of squared gradient elements (one slot per block: deterministic)

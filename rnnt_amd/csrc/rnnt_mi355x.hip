@@ -284,7 +284,55 @@ void launch_sweep(const Call& c, int b0, int nb, hipStream_t st) {
   }
 }
 
+// Which kernel takes the gradient pass (measured at B=64, T=500, U=100: bytes read + written per second, flattered
+// alike by pruned rows):
+//   k_grad_flat<true>   16-byte rows that are no multiple of 512 bytes, and all of them up to 128 logits: 5.9-8.4 TB/s
+//                       for V = 32..128 (k_grad_small: 3.6-6.4), 8.0-8.3 for V = 132..300 (k_grad_span: 5.6-7.3)
+//   k_grad_small        dense tensors of up to 128 logits whose rows are no multiple of 16 bytes (V = 62: 6.3;
+//                       k_grad_flat<false> 4.6, k_grad 3.0)
+//   k_grad_flat<false>  such rows where k_grad_small cannot run (not dense, or more than 128 logits): 4.3-5.0
+//   k_grad_span         rows that are multiples of 512 bytes (V = 256: 8.5, 512: 9.1, 1024: 9.3; k_grad_flat 8.1-8.3)
+//   k_grad              everything else (unaligned utterances, more than 4096 logits, fewer than 32)
+void launch_flat(const Call& c, int b0, int nb, hipStream_t st) {
+  FlatGeom fg;
+  fg.maxT = c.maxT; fg.maxU1 = c.maxU1; fg.V = c.V; fg.blank = c.blank;
+  fg.rows_utt = c.maxT * c.maxU1;
+  fg.q256 = 256 / c.V; fg.r256 = 256 % c.V;
+  const long long total = (long long)fg.rows_utt * c.V, per_block = 4LL * kFlatChunksPerBlock;
+  fg.blocks_utt = (int)((total + per_block - 1) / per_block);
+  fg.table_rows = (int)(per_block / c.V) + 2;
+  fg.b0 = b0; fg.nblocks = nb * fg.blocks_utt; fg.nblocks_all = c.B * fg.blocks_utt;
+  fg.prune_log2 = g_prune_log2.load(std::memory_order_relaxed);
+  fg.xstride = c.xstride; fg.gstride = c.gstride;
+  const dim3 grid((unsigned)fg.nblocks), blk(kFlatWaves * 64);
+  const size_t lds = sizeof(float4) * (size_t)fg.table_rows;
+  if (c.V % 4 == 0)
+    k_grad_flat<true><<<grid, blk, lds, st>>>(c.logits, c.grad, c.labels, c.in_len, c.lab_len, c.grad_scale, fg, c.w);
+  else
+    k_grad_flat<false><<<grid, blk, lds, st>>>(c.logits, c.grad, c.labels, c.in_len, c.lab_len, c.grad_scale, fg, c.w);
+}
+
+void zero_cropped_frames(const Call& c, int b0, hipStream_t st) {
+  if (c.t_off > 0 && b0 == 0) {
+    const size_t n = (size_t)c.t_off * c.maxU1 * c.V;
+    const unsigned per_b = (unsigned)((n + 1023) / 1024);
+    k_zero_frames<<<dim3(per_b, (unsigned)c.B), 256, 0, st>>>(c.grad - n, c.gstride, n);
+  }
+}
+
 void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
+  // k_grad_flat only needs every utterance (of the logits and of the gradient) to start on a 16-byte boundary
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(c.logits) | reinterpret_cast<uintptr_t>(c.grad) |
+                         (uintptr_t)(c.xstride * 4) | (uintptr_t)(c.gstride * 4);
+  bool flat_ok = bits % 16 == 0 && c.V >= 32 && c.V <= 4096;
+#ifdef RNNT_NO_FLAT
+  flat_ok = false;
+#endif
+  if (flat_ok && c.V % 4 == 0 && (c.V % 128 != 0 || c.V <= 128)) {
+    zero_cropped_frames(c, b0, st);
+    launch_flat(c, b0, nb, st);
+    return;
+  }
   if (b0 == 0 && nb == c.B && use_small(c, c.grad)) {
     int blocks;
     const SmallGeom g = small_geom(c, &blocks);
@@ -295,34 +343,12 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
     RNNT_SMALL_DISPATCH(k_grad_small, c.V, true, blocks, lds, st, x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
     return;
   }
-  if (c.t_off > 0 && b0 == 0) {  // gradient of the cropped frames
-    const size_t n = (size_t)c.t_off * c.maxU1 * c.V;
-    const unsigned per_b = (unsigned)((n + 1023) / 1024);
-    k_zero_frames<<<dim3(per_b, (unsigned)c.B), 256, 0, st>>>(c.grad - n, c.gstride, n);
-  }
-  const RowCfg cfg = sub_cfg(c, c.grad, b0, nb);
-  // Rows that are a whole number of 512-byte pieces go to k_grad_span (lanes tied to rows), every other aligned row
-  // of 32..4096 logits to k_grad_flat (lanes tied to memory).  Measured at B=64, T=500, U=100 (bytes read + written
-  // per second, flattered alike by pruned rows; span / flat): V=132 5.6 / 8.2, 160 7.3 / 8.3, 200 5.6 / 8.3,
-  // 300 6.6 / 8.0 against V=256 8.5 / 8.3, 512 9.1 / 8.2, 1024 9.3 / 8.1 TB/s.
-#ifndef RNNT_NO_FLAT
-  if (cfg.vec == 4 && c.V >= 32 && c.V <= 4096 && (c.V % 128 != 0 || c.V <= 128)) {
-    FlatGeom fg;
-    fg.maxT = c.maxT; fg.maxU1 = c.maxU1; fg.V = c.V; fg.blank = c.blank;
-    fg.rows_utt = c.maxT * c.maxU1;
-    fg.nchunk = c.V / 4;
-    fg.q64 = 64 / fg.nchunk; fg.r64 = 64 % fg.nchunk;
-    const long long total = (long long)fg.rows_utt * fg.nchunk;
-    fg.blocks_utt = (int)((total + kFlatChunksPerBlock - 1) / kFlatChunksPerBlock);
-    fg.table_rows = kFlatChunksPerBlock / fg.nchunk + 2;
-    fg.b0 = b0; fg.nblocks = nb * fg.blocks_utt; fg.nblocks_all = c.B * fg.blocks_utt;
-    fg.prune_log2 = g_prune_log2.load(std::memory_order_relaxed);
-    fg.xstride = c.xstride; fg.gstride = c.gstride;
-    k_grad_flat<<<dim3((unsigned)fg.nblocks), dim3(kFlatWaves * 64), sizeof(float4) * (size_t)fg.table_rows, st>>>(
-        c.logits, c.grad, c.labels, c.in_len, c.lab_len, c.grad_scale, fg, c.w);
+  zero_cropped_frames(c, b0, st);
+  if (flat_ok && c.V % 4 != 0) {
+    launch_flat(c, b0, nb, st);
     return;
   }
-#endif
+  const RowCfg cfg = sub_cfg(c, c.grad, b0, nb);
 #ifndef RNNT_NO_SPAN
   if (cfg.vec == 4 && c.V > 128 && c.V <= 4096) {
     // rows per wave chosen so that a wave owns about 32 KiB: lanes per row L, 16-byte chunks per lane NC, row groups NG
