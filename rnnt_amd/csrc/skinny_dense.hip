@@ -82,37 +82,56 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
   float bv[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) bv[j] = (bias && col + j < Nd) ? bias[col + j] : 0.f;
-  // Plain loop, many resident waves: keeping a whole 32 x K slab (or two) of a in registers ahead of the MFMAs
-  // measured 0-35 % slower (fewer waves per SIMD); the limiter is the 16-byte-per-row access to a.
+  // One round = 32 columns (one 128-byte line of every row): the four 16-byte pieces a lane takes from its row's
+  // line are requested back to back, so the line is fetched once instead of once per piece.  The rounds of all the
+  // wave's tiles form one software pipeline: the loads of the next round (of this tile or of the wave's next one)
+  // are issued before the matrix instructions of the current round, so that a wave's memory latency overlaps its
+  // own arithmetic (16 registers; keeping a whole 32 x K slab ahead cost too many resident waves).  Only where
+  // the registers allow it (up to 64 output columns, no activation gradient to fold in): K=100, N=62 forward
+  // 441 -> 375 us; with 128 output columns or the second operand of the data gradient it spills and loses.
+  // (Knock-out timings of this kernel at K=100: N=62 373 us = 207 us of arithmetic alone (137 if the matrix pipe
+  // never waited) + ~45 loads + ~120 stores and what does not overlap; N=100 610 us = 416 (274) + ...: the
+  // matrix pipe at the float32 rate is the bound, memory is not.)
+  constexpr bool PIPE = !DACT && NT <= 2;
   const long long tiles = (M + 31) / 32;
   const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
-  for (long long tile = wave0; tile < tiles; tile += nwaves) {
-    const long long m0 = tile * 32;
-    const long long mrow = m0 + l32;
+  float nxt[4][4], nz[4][4];
+  auto issue = [&](long long tile, int k0) {
+    const long long mrow = tile * 32 + l32;
     const bool row_ok = mrow < M;
     const float* ap = a + (size_t)(row_ok ? mrow : 0) * Kd + 4 * h;
     const float* zp = DACT ? z + (size_t)(row_ok ? mrow : 0) * Kd + 4 * h : nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kq = k0 + 8 * q;
+      if (kq < Kp) {  // uniform
+#ifdef RNNT_DENSE_NO_LOAD  // timing experiment (wrong results)
+        for (int i = 0; i < 4; ++i) nxt[q][i] = (float)(kq + i), nz[q][i] = 0.5f;
+#else
+        load4<AVEC>(ap + kq, kq + 4 * h, Kd, row_ok, nxt[q]);
+        if (DACT) load4<AVEC>(zp + kq, kq + 4 * h, Kd, row_ok, nz[q]);
+#endif
+      }
+    }
+  };
+  if (PIPE && wave0 < tiles) issue(wave0, 0);
+  for (long long tile = wave0; tile < tiles; tile += nwaves) {
+    const long long m0 = tile * 32;
     f16v acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    // 32 columns (one 128-byte line of every row) per round: the four 16-byte pieces a lane takes from its row's
-    // line are requested back to back, so the line is fetched once instead of once per piece
     for (int k0 = 0; k0 < Kp; k0 += 32) {
+      if (!PIPE) issue(tile, k0);
       float av[4][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kq = k0 + 8 * q;
-        if (kq < Kp) {  // uniform
-          load4<AVEC>(ap + kq, kq + 4 * h, Kd, row_ok, av[q]);
-          if (DACT) {
-            float zv[4];
-            load4<AVEC>(zp + kq, kq + 4 * h, Kd, row_ok, zv);
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[q][i] *= 1.f - zv[i] * zv[i];
-          }
-        }
+        for (int i = 0; i < 4; ++i) av[q][i] = DACT ? nxt[q][i] * (1.f - nz[q][i] * nz[q][i]) : nxt[q][i];
+      if (PIPE) {  // next round: of this tile, or the first one of the wave's next tile
+        if (k0 + 32 < Kp) issue(tile, k0 + 32);
+        else if (tile + nwaves < tiles) issue(tile + nwaves, 0);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -123,7 +142,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
             const float* wr = wl + (kq + 4 * h + i) * pitch + col;
 #pragma unroll
             for (int j = 0; j < NT; ++j)
+#ifdef RNNT_DENSE_NO_MFMA  // timing experiment (wrong results)
+              acc[j][i] += av[q][i] * wr[j];
+#else
               acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][i], wr[j], acc[j], 0, 0, 0);
+#endif
           }
         }
       }
@@ -143,6 +166,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
         o[j] = v;
       }
       float* yp = y + (size_t)m * Nd + col;
+#ifdef RNNT_DENSE_NO_STORE  // timing experiment (wrong results)
+      {
+        float keep = 0.f;
+        for (int j = 0; j < NT; ++j) keep += o[j];
+        if (keep == 1.2345f) yp[0] = keep;
+      }
+      continue;
+#endif
       if (NT == 4 && yvec_ok && col + 4 <= Nd) {
         const f4v t = {o[0], o[1], o[2], o[3]};
         *reinterpret_cast<f4v*>(yp) = t;
