@@ -232,6 +232,93 @@ __global__ __launch_bounds__(kBlock) void k_fcj_bwd(const float* __restrict__ pe
   }
 }
 
+// The same pass without a barrier per frame: thread j owns the 16-byte column group hc = j % (H/4) for good and the
+// label positions g, g + G, g + 2G, ... (g = j / (H/4), G = 256 / (H/4) row groups per block), so that a pass of
+// the block over G consecutive rows of dh is one contiguous run and the sum over u of a thread's own rows stays in
+// its registers.  Per frame a thread adds its rows up (su), per label position it adds the frames up (acc, ->
+// partial as in k_fcj_bwd); only the G partial sums per (frame, column) go through LDS, once, at the end of the
+// block, and are added in order of g (fixed summation order).  Label positions are walked in tiles of G * NG rows.
+template <int NG>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_fcj_bwd_cols(const float* __restrict__ pe, const float* __restrict__ pd,
+                                                         const float* __restrict__ dh, float* __restrict__ dpe,
+                                                         float* __restrict__ partial, int T, int U1, int H,
+                                                         int nchunk) {
+  extern __shared__ float lds[];
+  const int hv = H >> 2, G = kBlock / hv;
+  float* pe_s = lds;                        // [kFrames][H]
+  float* part_s = lds + kFrames * H;        // [kFrames][G][H]
+  const int b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk;
+  const int t0 = chunk * kFrames, nt = min(kFrames, T - t0);
+  for (int i = threadIdx.x; i < kFrames * H; i += kBlock)
+    pe_s[i] = (i < nt * H) ? pe[((size_t)b * T + t0) * H + i] : 0.f;
+  __syncthreads();
+  const int j = threadIdx.x;
+  const bool on = j < G * hv;
+  const int g = on ? j / hv : 0, hc = on ? j - g * hv : 0;
+  const float* pdb = pd + (size_t)b * U1 * H + 4 * hc;
+  const float* dhb = dh + ((size_t)b * T + t0) * U1 * H + 4 * hc;
+  float* part = partial + ((size_t)b * nchunk + chunk) * U1 * H + 4 * hc;
+  f4v su[kFrames];
+#pragma unroll
+  for (int tt = 0; tt < kFrames; ++tt) su[tt] = f4v{0.f, 0.f, 0.f, 0.f};
+  for (int u0 = 0; u0 < U1; u0 += G * NG) {
+    f4v pdv[NG], acc[NG];
+    bool ok[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int u = u0 + k * G + g;
+      ok[k] = on && u < U1;
+      acc[k] = f4v{0.f, 0.f, 0.f, 0.f};
+      pdv[k] = ok[k] ? *reinterpret_cast<const f4v*>(pdb + (size_t)u * H) : f4v{0.f, 0.f, 0.f, 0.f};
+    }
+    // the loads of frame tt + 1 are in flight while frame tt is worked on (two register sets; the scheduling
+    // barriers keep the compiler from hoisting more frames than that: all eight would cost a resident block)
+    f4v dv[2][NG];
+    auto fetch = [&](int tt, f4v (&d)[NG]) {
+      const float* src = dhb + (size_t)tt * U1 * H;
+#pragma unroll
+      for (int k = 0; k < NG; ++k)
+        d[k] = (ok[k] && tt < nt)
+                   ? __builtin_nontemporal_load(reinterpret_cast<const f4v*>(src + (size_t)(u0 + k * G + g) * H))
+                   : f4v{0.f, 0.f, 0.f, 0.f};
+    };
+    fetch(0, dv[0]);
+#pragma unroll
+    for (int tt = 0; tt < kFrames; ++tt) {
+      if (tt + 1 < kFrames) fetch(tt + 1, dv[(tt + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tt < nt) {  // uniform
+        const f4v pev = *reinterpret_cast<const f4v*>(pe_s + tt * H + 4 * hc);
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float hh = tanh_fast(pev[e] + pdv[k][e]);
+            const float d = dv[tt & 1][k][e] * __builtin_fmaf(-hh, hh, 1.f);
+            acc[k][e] += d;
+            su[tt][e] += d;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k)
+      if (ok[k]) *reinterpret_cast<f4v*>(part + (size_t)(u0 + k * G + g) * H) = acc[k];
+  }
+  if (on) {
+#pragma unroll
+    for (int tt = 0; tt < kFrames; ++tt) *reinterpret_cast<f4v*>(part_s + ((size_t)tt * G + g) * H + 4 * hc) = su[tt];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nt * H; i += kBlock) {
+    const int tt = i / H, hcol = i - tt * H;
+    float sum = 0.f;
+    for (int gg = 0; gg < G; ++gg) sum += part_s[((size_t)tt * G + gg) * H + hcol];
+    dpe[((size_t)b * T + t0) * H + i] = sum;
+  }
+}
+
 // dpd[b][i] = sum over the frame chunks of partial[b][chunk][i], i in [0, U1*H)
 __global__ __launch_bounds__(kBlock) void k_fcj_bwd_reduce(const float* __restrict__ partial,
                                                            float* __restrict__ dpd, int per_b, int nchunk,
@@ -246,6 +333,12 @@ __global__ __launch_bounds__(kBlock) void k_fcj_bwd_reduce(const float* __restri
   dpd[i] = s;
 }
 
+#ifndef RNNT_FCJ_NG_SMALL
+#define RNNT_FCJ_NG_SMALL 4
+#endif
+#ifndef RNNT_FCJ_NG_LARGE
+#define RNNT_FCJ_NG_LARGE 4
+#endif
 constexpr int kMaxH = 1536;  // tile + [kFrames][rg][H] + [kFrames][H] must fit the 160 KiB of LDS (rg = 1 when H > 512)
 
 int check_dims(int B, int T, int U1, int H) {
@@ -312,6 +405,29 @@ int rnnt_mi355x_fc_joint_backward(const float* pe, const float* pd, const float*
   float* partial = static_cast<float*>(workspace);
   const int ng = (rows * H / (vec ? 4 : 1) + kBlock - 1) / kBlock;  // groups per thread and tile: <= 8 (vec) or 32
   const dim3 grid((unsigned)(B * nchunk));
+#ifndef RNNT_FCJ_NO_COLS
+  if (vec && reinterpret_cast<uintptr_t>(pe) % 16 == 0 && H / 4 <= kBlock) {
+    const int G = kBlock / (H / 4);
+    const size_t lds2 = sizeof(float) * ((size_t)kFrames * H + (size_t)kFrames * G * H);
+#define FCJ_COLS(N)                                                                                           \
+  do {                                                                                                        \
+    if (lds2 > 48 * 1024 &&                                                                                   \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcj_bwd_cols<N>),                                \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)            \
+      return RNNT_MI355X_LAUNCH_FAILURE;                                                                      \
+    k_fcj_bwd_cols<N><<<grid, kBlock, lds2, st>>>(pe, pd, dh, dpe, partial, T, U1, H, nchunk);                \
+  } while (0)
+    // rows per thread and tile: few tiles (pd is re-read per tile), few registers
+    const int rows_per_pass = G;
+    const int need = (U1 + rows_per_pass - 1) / rows_per_pass;  // rows a thread owns in all
+    if (need <= RNNT_FCJ_NG_SMALL) FCJ_COLS(RNNT_FCJ_NG_SMALL);
+    else FCJ_COLS(RNNT_FCJ_NG_LARGE);
+#undef FCJ_COLS
+    const long long total2 = (long long)B * U1 * H;
+    k_fcj_bwd_reduce<<<(unsigned)((total2 + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, dpd, U1 * H, nchunk, total2);
+    return status();
+  }
+#endif
 #define FCJ_BWD(N, V)                                                                                       \
   do {                                                                                                      \
     if (lds > 48 * 1024 &&                                                                                  \
