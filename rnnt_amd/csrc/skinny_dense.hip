@@ -239,6 +239,156 @@ __global__ __launch_bounds__(kBlock) void k_dense_wgrad(const float* __restrict_
   }
 }
 
+// The same partial weight gradient with the operands staged through LDS.  k_dense_wgrad feeds every matrix
+// instruction from global memory with 4-byte loads (a lane needs x(m, k) for its own k down the rows): measured
+// 522 us at K=100, N=62 and 1364 us at N=100 for M = 1.6 M rows, three to four times what the matrix pipe or the
+// memory system needs.  Here a block copies slabs of 32 rows of x and of G -- contiguous in memory, so the copy is
+// flat and coalesced -- into LDS (double buffered: the next slab's loads are in flight during this slab's
+// arithmetic) and the lanes read their operands from there (consecutive k / n in a half-wavefront: no bank
+// conflicts).  Wave w owns rows 32w..32w+31 of P, and with KPW = 2 (K = 128: 129 rows with the bias row) also
+// rows 32(w+4).. .
+template <int NT, bool DACT, int KPW>
+__global__ __launch_bounds__(kBlock) void k_dense_wgrad_lds(const float* __restrict__ x, const float* __restrict__ yout,
+                                                            const float* __restrict__ dy, float* __restrict__ partial,
+                                                            long long M, int K, int N, int KT, long long rows_per_block,
+                                                            bool xvec_ok, bool gvec_ok) {
+  extern __shared__ float slab[];  // [2][32*K + 32*N]
+  constexpr int Np = 32 * NT;
+  const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  const int nx = 32 * K, ng = 32 * N, per_buf = nx + ng;
+  const int nslab = r1 > r0 ? (int)((r1 - r0 + 31) / 32) : 0;
+
+  // staging registers: up to 4 float4 (or 16 floats) of x, of dy and of y per thread (K, N <= 128)
+  float xr[4][4], gr[4][4], yr[4][4];
+  auto fetch = [&](int s) {
+    const long long m0 = r0 + 32LL * s;
+    const long long left = r1 - m0;  // rows of this slab inside the block's range
+    const float* xs = x + (size_t)m0 * K;
+    const float* gs = dy + (size_t)m0 * N;
+    const float* ys = DACT ? yout + (size_t)m0 * N : nullptr;
+    const long long xe = (left < 32 ? left : 32) * K, ge = (left < 32 ? left : 32) * N;  // valid elements
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = 4 * (threadIdx.x + kBlock * i);
+      if (e < nx) {
+        if (xvec_ok && e + 4 <= xe) {
+          const f4v t = *reinterpret_cast<const f4v*>(xs + e);
+          xr[i][0] = t[0]; xr[i][1] = t[1]; xr[i][2] = t[2]; xr[i][3] = t[3];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xr[i][q] = (e + q < xe) ? xs[e + q] : 0.f;
+        }
+      }
+      if (e < ng) {
+        if (gvec_ok && e + 4 <= ge) {
+          const f4v t = *reinterpret_cast<const f4v*>(gs + e);
+          gr[i][0] = t[0]; gr[i][1] = t[1]; gr[i][2] = t[2]; gr[i][3] = t[3];
+          if (DACT) {
+            const f4v u = *reinterpret_cast<const f4v*>(ys + e);
+            yr[i][0] = u[0]; yr[i][1] = u[1]; yr[i][2] = u[2]; yr[i][3] = u[3];
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            gr[i][q] = (e + q < ge) ? gs[e + q] : 0.f;
+            if (DACT) yr[i][q] = (e + q < ge) ? ys[e + q] : 0.f;
+          }
+        }
+      }
+    }
+  };
+  auto stage = [&](int buf) {
+    float* xs = slab + (size_t)buf * per_buf;
+    float* gs = xs + nx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = 4 * (threadIdx.x + kBlock * i);
+      if (e < nx) {  // nx and ng are multiples of 32: whole float4
+        const f4v t = {xr[i][0], xr[i][1], xr[i][2], xr[i][3]};
+        *reinterpret_cast<f4v*>(xs + e) = t;
+      }
+      if (e < ng) {
+        f4v t = {gr[i][0], gr[i][1], gr[i][2], gr[i][3]};
+        if (DACT) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t[q] *= 1.f - yr[i][q] * yr[i][q];
+        }
+        *reinterpret_cast<f4v*>(gs + e) = t;
+      }
+    }
+  };
+
+  f16v acc[KPW][NT];
+#pragma unroll
+  for (int p = 0; p < KPW; ++p)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][j][r] = 0.f;
+  // this lane's row of P per k-tile: a column of x, the row of ones (bias) or nothing
+  int kx[KPW], kmode[KPW];  // mode 0: read x, 1: ones, 2: zero
+#pragma unroll
+  for (int p = 0; p < KPW; ++p) {
+    const int k = 32 * (wv + 4 * p) + l32;
+    kmode[p] = (wv + 4 * p >= KT) ? 2 : k < K ? 0 : k == K ? 1 : 2;
+    kx[p] = k < K ? k : 0;
+  }
+  int ncol[NT];
+  bool nok[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = 32 * j + l32;
+    nok[j] = n < N;
+    ncol[j] = nok[j] ? n : 0;
+  }
+
+  if (nslab > 0) {
+    fetch(0);
+    stage(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    if (s + 1 < nslab) fetch(s + 1);
+    const float* xs = slab + (size_t)(s & 1) * per_buf;
+    const float* gs = xs + nx;
+    if (wv < KT) {  // (a block's waves beyond the k-tiles only help with the copies)
+#pragma unroll 4
+      for (int st = 0; st < 16; ++st) {
+        const int m = 2 * st + h;
+        float bv[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float t = gs[m * N + ncol[j]];
+          bv[j] = nok[j] ? t : 0.f;
+        }
+#pragma unroll
+        for (int p = 0; p < KPW; ++p) {
+          const float t = xs[m * K + kx[p]];
+          const float a = kmode[p] == 0 ? t : kmode[p] == 1 ? 1.f : 0.f;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[p][j], 0, 0, 0);
+        }
+      }
+    }
+    if (s + 1 < nslab) stage((s + 1) & 1);
+    __syncthreads();
+  }
+  float* out = partial + (size_t)blockIdx.x * (32 * KT) * Np;
+#pragma unroll
+  for (int p = 0; p < KPW; ++p) {
+    const int kt = wv + 4 * p;
+    if (kt >= KT) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* o = out + (size_t)(32 * kt + mm_row(r, lane)) * Np + NT * 0 + l32;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) o[32 * j] = acc[p][j][r];
+    }
+  }
+}
+
 // dw[k][n] = sum over blocks of partial[blk][k][n] (k < K), db[n] = the same for row K.  16 lanes per output
 // element: lane q adds the partials of blocks q, q+16, ... in order, then the 16 sums are added pairwise in a
 // fixed pattern -- the result does not depend on scheduling.
@@ -362,11 +512,48 @@ int rnnt_mi355x_dense_backward(const float* x, const float* w, const float* y, c
     if (r != RNNT_MI355X_OK) return r;
   }
   if (dw) {
-    const int nt = nt_for(N), KT = (K + 1 + 31) / 32, nb = wgrad_blocks(M);
+    const int nt = nt_for(N), KT = (K + 1 + 31) / 32;
+    int nb = wgrad_blocks(M);
+    float* partial = static_cast<float*>(workspace);
+#ifndef RNNT_DENSE_WGRAD_OLD
+    {
+      // operands staged through LDS; a persistent grid of at most one resident round of blocks
+      const size_t lds = sizeof(float) * 2 * 32 * (size_t)(K + N);
+      const bool xv = reinterpret_cast<uintptr_t>(x) % 16 == 0;
+      const bool gv4 = reinterpret_cast<uintptr_t>(dy) % 16 == 0 && (act == 0 || reinterpret_cast<uintptr_t>(y) % 16 == 0);
+      long long rows = 0;
+      auto go = [&](auto kern) -> int {
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+          return RNNT_MI355X_LAUNCH_FAILURE;
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+          cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if ((long long)per_cu * cus < nb) nb = per_cu * cus;
+        rows = (M + nb - 1) / nb;
+        rows = (rows + 31) & ~31LL;
+        nb = (int)((M + rows - 1) / rows);
+        kern<<<nb, kBlock, lds, st>>>(x, y, dy, partial, M, K, N, KT, rows, xv, gv4);
+        return RNNT_MI355X_OK;
+      };
+      int r = RNNT_MI355X_OK;
+#define DENSE_WGRAD_LDS(NT)                                                             \
+  do {                                                                                  \
+    if (KT > 4) r = act == 1 ? go(k_dense_wgrad_lds<NT, true, 2>) : go(k_dense_wgrad_lds<NT, false, 2>); \
+    else r = act == 1 ? go(k_dense_wgrad_lds<NT, true, 1>) : go(k_dense_wgrad_lds<NT, false, 1>);        \
+  } while (0)
+      if (nt == 1) DENSE_WGRAD_LDS(1);
+      else if (nt == 2) DENSE_WGRAD_LDS(2);
+      else DENSE_WGRAD_LDS(4);
+#undef DENSE_WGRAD_LDS
+      if (r != RNNT_MI355X_OK) return r;
+    }
+#else
+    const bool gv = nvec_ok(dy, N, nt) && (act == 0 || nvec_ok(y, N, nt));
     long long rows = (M + nb - 1) / nb;
     rows = (rows + 7) & ~7LL;
-    const bool gv = nvec_ok(dy, N, nt) && (act == 0 || nvec_ok(y, N, nt));
-    float* partial = static_cast<float*>(workspace);
 #define DENSE_WGRAD(NT)                                                                                          \
   do {                                                                                                           \
     if (act == 1) k_dense_wgrad<NT, true><<<nb, kBlock, 0, st>>>(x, y, dy, partial, M, K, N, KT, rows, gv);       \
@@ -376,6 +563,7 @@ int rnnt_mi355x_dense_backward(const float* x, const float* w, const float* y, c
     else if (nt == 2) DENSE_WGRAD(2);
     else DENSE_WGRAD(4);
 #undef DENSE_WGRAD
+#endif
     const int total = (K + 1) * N * 16;
     k_dense_wgrad_reduce<<<(total + kBlock - 1) / kBlock, kBlock, 0, st>>>(partial, dw, db, K, N, 32 * KT, 32 * nt, nb);
   }
