@@ -103,7 +103,10 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
   // two columns per lane from 42 to 37 instructions per diagonal without changing its 92-96 ns; tools/lat_bench.hip
   // puts an independent instruction of this mix at 2-2.3 ns and v_exp_f32 / v_log_f32 at 3.8 ns on one wavefront,
   // i.e. ~45 ns per column for the arithmetic alone.
-  constexpr int P = K == 1 ? 16 : K == 2 ? 8 : 4;
+#ifndef RNNT_SWEEP_P2
+#define RNNT_SWEEP_P2 8
+#endif
+  constexpr int P = K == 1 ? 16 : K == 2 ? RNNT_SWEEP_P2 : 4;
   const int b = b0 + (blockIdx.x >> 1);
   const int dir = blockIdx.x & 1;
   const int lane = threadIdx.x;
