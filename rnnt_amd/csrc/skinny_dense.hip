@@ -62,15 +62,26 @@ __device__ __forceinline__ void loadn(const float* p, int col, int ncol, bool ro
 // g the upstream gradient and z the layer's forward output.  W arrives as wt[k][n] = W[k][n] (TRANS = false) or
 // W[n][k] (TRANS = true: the data gradient multiplies by W^T).  Kd = contraction length, Nd = output columns.
 // LDS: W zero-padded to [Kp][Np + 4].  Lane l of MFMA tile j owns output column NT*(l%32) + j.
+// Resident waves per SIMD asked of the compiler: 6 with up to 64 output columns (5 where the activation gradient is
+// folded in: 6 spills), 4 with 128 columns (two 32 x 64 accumulators more).  Blocks of 8 waves share one copy of
+// W in LDS: with 4-wave blocks the 55-68 KB of a 128-column W left room for two blocks = 2 waves per SIMD
+// (K=100, N=100 forward 495 -> 450 us; K=64, N=40 216 -> 185 us; K=100, N=62 unchanged within noise).
+#ifndef RNNT_DENSE_FWD_WPE
+#define RNNT_DENSE_FWD_WPE 6
+#endif
+#ifndef RNNT_DENSE_FWD_BLOCK
+#define RNNT_DENSE_FWD_BLOCK 512
+#endif
+constexpr int kFwdBlock = RNNT_DENSE_FWD_BLOCK, kFwdWaves = kFwdBlock / 64;
 template <int NT, int AVEC, bool DACT, bool TRANS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_dense_fwd(const float* __restrict__ a, const float* __restrict__ z,
+__global__ __launch_bounds__(kFwdBlock) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? (DACT ? 5 : RNNT_DENSE_FWD_WPE) : 4))) void k_dense_fwd(const float* __restrict__ a, const float* __restrict__ z,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       float* __restrict__ y, long long M, int Kd, int Nd, int act,
                                                       bool yvec_ok) {
   extern __shared__ float wl[];
   constexpr int Np = 32 * NT, pitch = Np + 4;
   const int Kp = (Kd + 7) & ~7;
-  for (int i = threadIdx.x; i < Kp * Np; i += kBlock) {
+  for (int i = threadIdx.x; i < Kp * Np; i += kFwdBlock) {
     const int k = i / Np, n = i - k * Np;
     float v = 0.f;
     if (k < Kd && n < Nd) v = TRANS ? w[(size_t)n * Kd + k] : w[(size_t)k * Nd + n];
@@ -92,9 +103,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
   // (Knock-out timings of this kernel at K=100: N=62 373 us = 207 us of arithmetic alone (137 if the matrix pipe
   // never waited) + ~45 loads + ~120 stores and what does not overlap; N=100 610 us = 416 (274) + ...: the
   // matrix pipe at the float32 rate is the bound, memory is not.)
+#ifdef RNNT_DENSE_NO_PIPE
+  constexpr bool PIPE = false;
+#else
   constexpr bool PIPE = !DACT && NT <= 2;
+#endif
   const long long tiles = (M + 31) / 32;
-  const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  const long long wave0 = (long long)blockIdx.x * kFwdWaves + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * kFwdWaves;
   float nxt[4][4], nz[4][4];
   auto issue = [&](long long tile, int k0) {
     const long long mrow = tile * 32 + l32;
@@ -430,12 +445,12 @@ inline bool nvec_ok(const void* p, int ncol, int nt) {
 // round-robin, so a second, partial round of blocks would leave most of the device idle at the end).
 template <typename Kern>
 inline unsigned fwd_grid(long long M, Kern kern, size_t lds) {
-  const long long blocks = ((M + 31) / 32 + 3) / 4;
+  const long long blocks = ((M + 31) / 32 + kFwdWaves - 1) / kFwdWaves;
   int per_cu = 0, dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
     cus = 256;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kFwdBlock, lds) != hipSuccess || per_cu < 1) per_cu = 1;
   const long long resident = (long long)per_cu * cus;
   return (unsigned)(blocks < resident ? blocks : resident);
 }
@@ -463,7 +478,7 @@ int launch_fwd(const float* a, const float* z, const float* w, const float* bias
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
       return RNNT_MI355X_LAUNCH_FAILURE;                                                                         \
     const unsigned grid = fwd_grid(M, k_dense_fwd<NT, AV, DACT, TRANS>, lds);                                    \
-    k_dense_fwd<NT, AV, DACT, TRANS><<<grid, kBlock, lds, st>>>(a, z, w, bias, y, M, Kd, Nd, act, yv);           \
+    k_dense_fwd<NT, AV, DACT, TRANS><<<grid, kFwdBlock, lds, st>>>(a, z, w, bias, y, M, Kd, Nd, act, yv);           \
   } while (0)
 #define DENSE_FWD_AV(NT)              \
   do {                                \

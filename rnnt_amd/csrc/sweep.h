@@ -106,7 +106,13 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
 #ifndef RNNT_SWEEP_P2
 #define RNNT_SWEEP_P2 8
 #endif
-  constexpr int P = K == 1 ? 16 : K == 2 ? RNNT_SWEEP_P2 : 4;
+#ifndef RNNT_SWEEP_P4
+#define RNNT_SWEEP_P4 4
+#endif
+#ifndef RNNT_SWEEP_P8
+#define RNNT_SWEEP_P8 4
+#endif
+  constexpr int P = K == 1 ? 16 : K == 2 ? RNNT_SWEEP_P2 : K == 4 ? RNNT_SWEEP_P4 : K == 8 ? RNNT_SWEEP_P8 : 4;
   const int b = b0 + (blockIdx.x >> 1);
   const int dir = blockIdx.x & 1;
   const int lane = threadIdx.x;
