@@ -262,21 +262,27 @@ __global__ __launch_bounds__(kBlock) void k_dense_wgrad(const float* __restrict_
 // arithmetic) and the lanes read their operands from there (consecutive k / n in a half-wavefront: no bank
 // conflicts).  Wave w owns rows 32w..32w+31 of P, and with KPW = 2 (K = 128: 129 rows with the bias row) also
 // rows 32(w+4).. .
-template <int NT, bool DACT, int KPW>
-__global__ __launch_bounds__(kBlock) void k_dense_wgrad_lds(const float* __restrict__ x, const float* __restrict__ yout,
+#ifndef RNNT_WGRAD_WAVES
+#define RNNT_WGRAD_WAVES 8
+#endif
+template <int NT, bool DACT, int KPW, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_dense_wgrad_lds(const float* __restrict__ x, const float* __restrict__ yout,
                                                             const float* __restrict__ dy, float* __restrict__ partial,
                                                             long long M, int K, int N, int KT, long long rows_per_block,
                                                             bool xvec_ok, bool gvec_ok) {
   extern __shared__ float slab[];  // [2][32*K + 32*N]
-  constexpr int Np = 32 * NT;
-  const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+  // WAVES = 8: waves 4..7 take the upper half of the column tiles of the same rows of P, so twice as many waves
+  // share a slab (residency is limited by the slabs in LDS) and each holds half the accumulators.
+  constexpr int Np = 32 * NT, CS = WAVES / 4, NTW = NT / CS, TB = WAVES * 64, NI = 4 / CS;
+  static_assert(WAVES == 4 || (WAVES == 8 && NT % 2 == 0), "8 waves split the column tiles in two");
+  const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5, wv = (threadIdx.x >> 6) & 3, wc = threadIdx.x >> 8;
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
   const int nx = 32 * K, ng = 32 * N, per_buf = nx + ng;
   const int nslab = r1 > r0 ? (int)((r1 - r0 + 31) / 32) : 0;
 
   // staging registers: up to 4 float4 (or 16 floats) of x, of dy and of y per thread (K, N <= 128)
-  float xr[4][4], gr[4][4], yr[4][4];
+  float xr[NI][4], gr[NI][4], yr[NI][4];
   auto fetch = [&](int s) {
     const long long m0 = r0 + 32LL * s;
     const long long left = r1 - m0;  // rows of this slab inside the block's range
@@ -285,8 +291,8 @@ __global__ __launch_bounds__(kBlock) void k_dense_wgrad_lds(const float* __restr
     const float* ys = DACT ? yout + (size_t)m0 * N : nullptr;
     const long long xe = (left < 32 ? left : 32) * K, ge = (left < 32 ? left : 32) * N;  // valid elements
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = 4 * (threadIdx.x + kBlock * i);
+    for (int i = 0; i < NI; ++i) {
+      const int e = 4 * (threadIdx.x + TB * i);
       if (e < nx) {
         if (xvec_ok && e + 4 <= xe) {
           const f4v t = *reinterpret_cast<const f4v*>(xs + e);
@@ -318,8 +324,8 @@ __global__ __launch_bounds__(kBlock) void k_dense_wgrad_lds(const float* __restr
     float* xs = slab + (size_t)buf * per_buf;
     float* gs = xs + nx;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = 4 * (threadIdx.x + kBlock * i);
+    for (int i = 0; i < NI; ++i) {
+      const int e = 4 * (threadIdx.x + TB * i);
       if (e < nx) {  // nx and ng are multiples of 32: whole float4
         const f4v t = {xr[i][0], xr[i][1], xr[i][2], xr[i][3]};
         *reinterpret_cast<f4v*>(xs + e) = t;
@@ -335,11 +341,11 @@ __global__ __launch_bounds__(kBlock) void k_dense_wgrad_lds(const float* __restr
     }
   };
 
-  f16v acc[KPW][NT];
+  f16v acc[KPW][NTW];
 #pragma unroll
   for (int p = 0; p < KPW; ++p)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[p][j][r] = 0.f;
   // this lane's row of P per k-tile: a column of x, the row of ones (bias) or nothing
@@ -350,11 +356,11 @@ __global__ __launch_bounds__(kBlock) void k_dense_wgrad_lds(const float* __restr
     kmode[p] = (wv + 4 * p >= KT) ? 2 : k < K ? 0 : k == K ? 1 : 2;
     kx[p] = k < K ? k : 0;
   }
-  int ncol[NT];
-  bool nok[NT];
+  int ncol[NTW];
+  bool nok[NTW];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = 32 * j + l32;
+  for (int j = 0; j < NTW; ++j) {
+    const int n = 32 * (wc * NTW + j) + l32;
     nok[j] = n < N;
     ncol[j] = nok[j] ? n : 0;
   }
@@ -372,9 +378,9 @@ __global__ __launch_bounds__(kBlock) void k_dense_wgrad_lds(const float* __restr
 #pragma unroll 4
       for (int st = 0; st < 16; ++st) {
         const int m = 2 * st + h;
-        float bv[NT];
+        float bv[NTW];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NTW; ++j) {
           const float t = gs[m * N + ncol[j]];
           bv[j] = nok[j] ? t : 0.f;
         }
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_wgrad_lds(const float* __restr
           const float t = xs[m * K + kx[p]];
           const float a = kmode[p] == 0 ? t : kmode[p] == 1 ? 1.f : 0.f;
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[p][j], 0, 0, 0);
+          for (int j = 0; j < NTW; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[p][j], 0, 0, 0);
         }
       }
     }
@@ -397,9 +403,9 @@ __global__ __launch_bounds__(kBlock) void k_dense_wgrad_lds(const float* __restr
     if (kt >= KT) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float* o = out + (size_t)(32 * kt + mm_row(r, lane)) * Np + NT * 0 + l32;
+      float* o = out + (size_t)(32 * kt + mm_row(r, lane)) * Np + 32 * wc * NTW + l32;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) o[32 * j] = acc[p][j][r];
+      for (int j = 0; j < NTW; ++j) o[32 * j] = acc[p][j][r];
     }
   }
 }
@@ -537,7 +543,7 @@ int rnnt_mi355x_dense_backward(const float* x, const float* w, const float* y, c
       const bool xv = reinterpret_cast<uintptr_t>(x) % 16 == 0;
       const bool gv4 = reinterpret_cast<uintptr_t>(dy) % 16 == 0 && (act == 0 || reinterpret_cast<uintptr_t>(y) % 16 == 0);
       long long rows = 0;
-      auto go = [&](auto kern) -> int {
+      auto go = [&](auto kern, int threads) -> int {
         if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
           return RNNT_MI355X_LAUNCH_FAILURE;
@@ -545,19 +551,20 @@ int rnnt_mi355x_dense_backward(const float* x, const float* w, const float* y, c
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
           cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         if ((long long)per_cu * cus < nb) nb = per_cu * cus;
         rows = (M + nb - 1) / nb;
         rows = (rows + 31) & ~31LL;
         nb = (int)((M + rows - 1) / rows);
-        kern<<<nb, kBlock, lds, st>>>(x, y, dy, partial, M, K, N, KT, rows, xv, gv4);
+        kern<<<nb, threads, lds, st>>>(x, y, dy, partial, M, K, N, KT, rows, xv, gv4);
         return RNNT_MI355X_OK;
       };
       int r = RNNT_MI355X_OK;
 #define DENSE_WGRAD_LDS(NT)                                                             \
   do {                                                                                  \
-    if (KT > 4) r = act == 1 ? go(k_dense_wgrad_lds<NT, true, 2>) : go(k_dense_wgrad_lds<NT, false, 2>); \
-    else r = act == 1 ? go(k_dense_wgrad_lds<NT, true, 1>) : go(k_dense_wgrad_lds<NT, false, 1>);        \
+    constexpr int WV = (NT) >= 2 ? RNNT_WGRAD_WAVES : 4;                                  \
+    if (KT > 4) r = act == 1 ? go(k_dense_wgrad_lds<NT, true, 2, WV>, 64 * WV) : go(k_dense_wgrad_lds<NT, false, 2, WV>, 64 * WV); \
+    else r = act == 1 ? go(k_dense_wgrad_lds<NT, true, 1, WV>, 64 * WV) : go(k_dense_wgrad_lds<NT, false, 1, WV>, 64 * WV);        \
   } while (0)
       if (nt == 1) DENSE_WGRAD_LDS(1);
       else if (nt == 2) DENSE_WGRAD_LDS(2);
