@@ -410,6 +410,175 @@ __global__ __launch_bounds__(WAVES * 64) void k_dense_wgrad_lds(const float* __r
   }
 }
 
+// The weight gradient without LDS staging.  Which row of P an accumulator row stands for, and which column an
+// accumulator column, is free: with KV accumulators down and NV across, row r of accumulator i is k = KV*r + i and
+// column c of accumulator j is n = NV*CS*c + NV*cs + j (cs = the wave's column share when 128 columns are split
+// over CS = 2 waves).  Lane (r, h) then needs x(m, KV*r .. KV*r+KV-1) and G(m, its NV columns) of row
+// m = m0 + 2*step + h: ONE 16-byte and one 8-byte load of consecutive addresses -- a wavefront reads two whole
+// rows of x and of G per step, in the order they lie in memory -- feed KV*NV matrix instructions.  No LDS, no
+// barrier, no transposition; a ring of D steps keeps the loads ahead of their use.  The bias gradient is the
+// column sum of G: two additions per step on the vector unit instead of a row of ones in the product.
+// Every wavefront (pair) works on its own range of rows; the 4 / CS partial sums of a block meet in LDS at the end.
+// (Staged through LDS, k_dense_wgrad_lds, K=100 N=62 took 385 us: 137 us with neither the global loads nor the matrix
+// instructions -- LDS traffic and barriers -- 306 us without the loads, 260 us without the matrix instructions.)
+#ifndef RNNT_WGRAD_DEPTH
+#define RNNT_WGRAD_DEPTH 8
+#endif
+template <int KV, int NV, int CS, bool DACT, bool VEC>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KV * NV >= 8 ? 2 : 3))) void k_dense_wgrad_direct(const float* __restrict__ x, const float* __restrict__ yout,
+                                                               const float* __restrict__ dy, float* __restrict__ partial,
+                                                               long long M, int K, int N, int KT, long long rows_per_group) {
+  constexpr int D = RNNT_WGRAD_DEPTH, GROUPS = 4 / CS, NACC = KV * NV * 16;
+  extern __shared__ float red[];  // [CS][NACC * 64 + NV * 64]
+  const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+  const int cs = wv % CS, grp = wv / CS;
+  const long long r0 = ((long long)blockIdx.x * GROUPS + grp) * rows_per_group;  // even
+  const long long left = M - r0 < rows_per_group ? M - r0 : rows_per_group;
+  const int nrows = left > 0 ? (int)left : 0, nsteps = (nrows + 1) >> 1;
+  const int kcol = KV * l32, ncol = NV * CS * l32 + NV * cs;
+  // columns beyond K / N: loaded from a clamped column and multiplied away
+  bool kok[KV], nok[NV];
+  int kc[KV], nc[NV];
+#pragma unroll
+  for (int i = 0; i < KV; ++i) kok[i] = kcol + i < K, kc[i] = kok[i] ? kcol + i : 0;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) nok[j] = ncol + j < N, nc[j] = nok[j] ? ncol + j : 0;
+
+  // this lane's rows are r0 + h, r0 + h + 2, ...: `last` is the step of the last one
+  const bool has = nrows > h;
+  const int last = has ? (nrows - 1 - h) >> 1 : 0;
+  const size_t row0 = has ? (size_t)(r0 + h) : 0;
+  const float* xb = x + row0 * K;
+  const float* gb = dy + row0 * N;
+  const float* yb = DACT ? yout + row0 * N : nullptr;
+  float xa[D][KV], ga[D][NV], ya[D][NV];
+  auto load_step = [&](int st, float (&xv)[KV], float (&gv)[NV], float (&yv)[NV]) {
+    // steps beyond the lane's last row re-read that row (a row that exists); their values are dropped at use
+    const unsigned stc = (unsigned)(st < last ? st : last);
+    const float* xp = xb + (size_t)stc * (unsigned)(2 * K);
+    const float* gp = gb + (size_t)stc * (unsigned)(2 * N);
+    const float* yp = DACT ? yb + (size_t)stc * (unsigned)(2 * N) : nullptr;
+    if (VEC) {  // K % KV == 0, N % NV == 0, aligned: a lane's columns are all inside or all outside
+      if (KV == 4) {
+        const f4v t = *reinterpret_cast<const f4v*>(xp + kc[0]);
+        xv[0] = t[0]; xv[1] = t[1]; xv[2 % KV] = t[2]; xv[3 % KV] = t[3];
+      } else if (KV == 2) {
+        const f2v t = *reinterpret_cast<const f2v*>(xp + kc[0]);
+        xv[0] = t[0]; xv[1 % KV] = t[1];
+      } else {
+        xv[0] = xp[kc[0]];
+      }
+      if (NV == 2) {
+        const f2v t = *reinterpret_cast<const f2v*>(gp + nc[0]);
+        gv[0] = t[0]; gv[1 % NV] = t[1];
+        if (DACT) {
+          const f2v u = *reinterpret_cast<const f2v*>(yp + nc[0]);
+          yv[0] = u[0]; yv[1 % NV] = u[1];
+        }
+      } else {
+        gv[0] = gp[nc[0]];
+        if (DACT) yv[0] = yp[nc[0]];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < KV; ++i) xv[i] = xp[kc[i]];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        gv[j] = gp[nc[j]];
+        if (DACT) yv[j] = yp[nc[j]];
+      }
+    }
+  };
+
+  f16v acc[KV][NV];
+  float bsum[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    bsum[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KV; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  // The ring fills during a first pass of D steps that multiply zeros: with the first loads issued ahead of the
+  // loop instead, the compiler orders them by kind, and the loop's first wait then has to drain half the ring on
+  // every pass.
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+#pragma unroll
+    for (int i = 0; i < KV; ++i) xa[d][i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) ga[d][j] = ya[d][j] = 0.f;
+  }
+  for (int s = -D; s < nsteps; s += D) {  // steps beyond nsteps hold zeros
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const bool ok = has && s >= 0 && s + d <= last;
+      float g[NV], xv[KV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const float t = DACT ? ga[d][j] * (1.f - ya[d][j] * ya[d][j]) : ga[d][j];
+        g[j] = (ok && nok[j]) ? t : 0.f;
+        bsum[j] += g[j];
+      }
+#pragma unroll
+      for (int i = 0; i < KV; ++i) xv[i] = (ok && kok[i]) ? xa[d][i] : 0.f;
+#pragma unroll
+      for (int i = 0; i < KV; ++i)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[i], g[j], acc[i][j], 0, 0, 0);
+      load_step(s + d + D, xa[d], ga[d], ya[d]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // the block's row groups add up in LDS, one after the other (fixed order)
+  float* mine = red + (size_t)cs * (NACC * 64 + NV * 64);
+  for (int g = 0; g < GROUPS; ++g) {
+    if (grp == g) {
+      if (g > 0) {
+#pragma unroll
+        for (int i = 0; i < KV; ++i)
+#pragma unroll
+          for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += mine[((i * NV + j) * 16 + r) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) bsum[j] += mine[NACC * 64 + j * 64 + lane];
+      }
+      if (g < GROUPS - 1) {
+#pragma unroll
+        for (int i = 0; i < KV; ++i)
+#pragma unroll
+          for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[((i * NV + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) mine[NACC * 64 + j * 64 + lane] = bsum[j];
+      }
+    }
+    if (GROUPS > 1) __syncthreads();
+  }
+  if (grp != GROUPS - 1) return;
+  const int Np = 32 * NV * CS;
+  float* out = partial + (size_t)blockIdx.x * (32 * KT) * Np;
+#pragma unroll
+  for (int i = 0; i < KV; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = KV * mm_row(r, lane) + i;
+      if (k < K) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) out[(size_t)k * Np + ncol + j] = acc[i][j][r];
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const float t = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+    if (h == 0) out[(size_t)K * Np + ncol + j] = t;
+  }
+}
+
 // dw[k][n] = sum over blocks of partial[blk][k][n] (k < K), db[n] = the same for row K.  16 lanes per output
 // element: lane q adds the partials of blocks q, q+16, ... in order, then the 16 sums are added pairwise in a
 // fixed pattern -- the result does not depend on scheduling.
@@ -536,7 +705,50 @@ int rnnt_mi355x_dense_backward(const float* x, const float* w, const float* y, c
     const int nt = nt_for(N), KT = (K + 1 + 31) / 32;
     int nb = wgrad_blocks(M);
     float* partial = static_cast<float*>(workspace);
-#ifndef RNNT_DENSE_WGRAD_OLD
+#ifndef RNNT_WGRAD_LDS
+    {
+      const int kv = K <= 32 ? 1 : K <= 64 ? 2 : 4, nv = nt >= 2 ? 2 : 1, cs = nt == 4 ? 2 : 1;
+      const bool al = (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
+                       (act == 1 ? reinterpret_cast<uintptr_t>(y) : 0)) % 16 == 0;
+      const bool vec = al && K % kv == 0 && N % nv == 0;
+      const size_t lds = sizeof(float) * (size_t)cs * (kv * nv * 16 * 64 + nv * 64);
+      auto go = [&](auto kern) -> int {
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+          return RNNT_MI355X_LAUNCH_FAILURE;
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+          cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if ((long long)per_cu * cus < nb) nb = per_cu * cus;
+        const int groups = nb * (4 / cs);
+        long long rows = (M + groups - 1) / groups;
+        rows = (rows + 1) & ~1LL;
+        nb = (int)((M + rows * (4 / cs) - 1) / (rows * (4 / cs)));
+        kern<<<nb, kBlock, lds, st>>>(x, y, dy, partial, M, K, N, KT, rows);
+        return RNNT_MI355X_OK;
+      };
+      int r = RNNT_MI355X_OK;
+#define DENSE_WGRAD_DIRECT3(KV, NV, CS)                                                                       \
+  do {                                                                                                        \
+    if (act == 1) r = vec ? go(k_dense_wgrad_direct<KV, NV, CS, true, true>) : go(k_dense_wgrad_direct<KV, NV, CS, true, false>);   \
+    else r = vec ? go(k_dense_wgrad_direct<KV, NV, CS, false, true>) : go(k_dense_wgrad_direct<KV, NV, CS, false, false>);          \
+  } while (0)
+#define DENSE_WGRAD_DIRECT(KV)                       \
+  do {                                               \
+    if (nt == 1) DENSE_WGRAD_DIRECT3(KV, 1, 1);      \
+    else if (nt == 2) DENSE_WGRAD_DIRECT3(KV, 2, 1); \
+    else DENSE_WGRAD_DIRECT3(KV, 2, 2);              \
+  } while (0)
+      if (kv == 1) DENSE_WGRAD_DIRECT(1);
+      else if (kv == 2) DENSE_WGRAD_DIRECT(2);
+      else DENSE_WGRAD_DIRECT(4);
+#undef DENSE_WGRAD_DIRECT
+#undef DENSE_WGRAD_DIRECT3
+      if (r != RNNT_MI355X_OK) return r;
+    }
+#elif !defined(RNNT_DENSE_WGRAD_OLD)
     {
       // operands staged through LDS; a persistent grid of at most one resident round of blocks
       const size_t lds = sizeof(float) * 2 * 32 * (size_t)(K + N);
