@@ -7,8 +7,8 @@
 // reading x and writing y once.
 //
 //   k_dense_fwd   y = act(x W + b)                       (also the data gradient: dx = (dy * act') W^T)
-//   k_dense_wgrad partial dW, db per block: X^T (dy * act') contracted over a chunk of rows; a row of ones
-//                 appended to X^T makes the bias gradient one more row of the same product
+//   k_dense_wgrad_direct   partial dW, db per block: X^T (dy * act') contracted over the block's rows, operands
+//                 straight from global memory (whole rows per wavefront load); db = column sums on the vector unit
 //   k_dense_wgrad_reduce   sums the partials in block order (no atomics: bit-reproducible)
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -100,6 +100,10 @@ __global__ __launch_bounds__(kFwdBlock) __attribute__((amdgpu_waves_per_eu(NT <=
   // own arithmetic (16 registers; keeping a whole 32 x K slab ahead cost too many resident waves).  Only where
   // the registers allow it (up to 64 output columns, no activation gradient to fold in): K=100, N=62 forward
   // 441 -> 375 us; with 128 output columns or the second operand of the data gradient it spills and loses.
+  // (A variant with every load unconditional and on a ring of 8 steps whose waits the compiler counts -- the form
+  // k_dense_wgrad_direct below uses -- ran at the same 310-320 us: this kernel does not wait for its loads.  With its
+  // stores knocked out it takes 240 us; FETCH_SIZE shows 0.91 GB read for 0.65 GB of x: a row's 128-byte line is
+  // used by four loads that lie up to a step apart.)
   // (Knock-out timings of this kernel at K=100: N=62 373 us = 207 us of arithmetic alone (137 if the matrix pipe
   // never waited) + ~45 loads + ~120 stores and what does not overlap; N=100 610 us = 416 (274) + ...: the
   // matrix pipe at the float32 rate is the bound, memory is not.)
@@ -205,211 +209,8 @@ __global__ __launch_bounds__(kFwdBlock) __attribute__((amdgpu_waves_per_eu(NT <=
 }
 
 // Partial weight gradient of one block over its chunk of rows: P[k][n] = sum_m X(m,k) G(m,n) for k < K and
-// P[K][n] = sum_m G(m,n) (bias), G = dy or, with DACT, dy * (1 - y^2).  Wave w of the block owns rows
-// 32w..32w+31 of P (a wave may own none, or, for K = 128, two).  partial: [gridDim.x][Kr][Np], Kr = 32 * KT.
-template <int NT, bool DACT>
-__global__ __launch_bounds__(kBlock) void k_dense_wgrad(const float* __restrict__ x, const float* __restrict__ yout,
-                                                        const float* __restrict__ dy, float* __restrict__ partial,
-                                                        long long M, int K, int N, int KT, long long rows_per_block,
-                                                        bool gvec_ok) {
-  constexpr int Np = 32 * NT;
-  const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-  const int col = NT * l32;
-  const long long r0 = (long long)blockIdx.x * rows_per_block;
-  const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  for (int kt = wv; kt < KT; kt += 4) {  // KT <= 4 except for K = 128 (129 rows with the bias row)
-    const int kx = 32 * kt + l32;  // row of P (column of x) this lane feeds; kx == K is the row of ones
-    f16v acc[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    for (long long m0 = r0; m0 < r1; m0 += 8) {  // (alternating operand register sets measured slower here too)
-      float av[4], gv[4][NT];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const long long m = m0 + 4 * h + i;
-        const bool ok = m < r1;
-        av[i] = !ok ? 0.f : kx < K ? x[(size_t)m * K + kx] : kx == K ? 1.f : 0.f;
-        loadn<NT>(dy + (size_t)(ok ? m : 0) * N + col, col, N, ok, gvec_ok, gv[i]);
-        if (DACT) {
-          float yv[NT];
-          loadn<NT>(yout + (size_t)(ok ? m : 0) * N + col, col, N, ok, gvec_ok, yv);
-#pragma unroll
-          for (int j = 0; j < NT; ++j) gv[i][j] *= 1.f - yv[j] * yv[j];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], gv[i][j], acc[j], 0, 0, 0);
-    }
-    float* out = partial + (size_t)blockIdx.x * (32 * KT) * Np;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float* o = out + (size_t)(32 * kt + mm_row(r, lane)) * Np + col;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) o[j] = acc[j][r];
-    }
-  }
-}
-
-// The same partial weight gradient with the operands staged through LDS.  k_dense_wgrad feeds every matrix
-// instruction from global memory with 4-byte loads (a lane needs x(m, k) for its own k down the rows): measured
-// 522 us at K=100, N=62 and 1364 us at N=100 for M = 1.6 M rows, three to four times what the matrix pipe or the
-// memory system needs.  Here a block copies slabs of 32 rows of x and of G -- contiguous in memory, so the copy is
-// flat and coalesced -- into LDS (double buffered: the next slab's loads are in flight during this slab's
-// arithmetic) and the lanes read their operands from there (consecutive k / n in a half-wavefront: no bank
-// conflicts).  Wave w owns rows 32w..32w+31 of P, and with KPW = 2 (K = 128: 129 rows with the bias row) also
-// rows 32(w+4).. .
-#ifndef RNNT_WGRAD_WAVES
-#define RNNT_WGRAD_WAVES 8
-#endif
-template <int NT, bool DACT, int KPW, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_dense_wgrad_lds(const float* __restrict__ x, const float* __restrict__ yout,
-                                                            const float* __restrict__ dy, float* __restrict__ partial,
-                                                            long long M, int K, int N, int KT, long long rows_per_block,
-                                                            bool xvec_ok, bool gvec_ok) {
-  extern __shared__ float slab[];  // [2][32*K + 32*N]
-  // WAVES = 8: waves 4..7 take the upper half of the column tiles of the same rows of P, so twice as many waves
-  // share a slab (residency is limited by the slabs in LDS) and each holds half the accumulators.
-  constexpr int Np = 32 * NT, CS = WAVES / 4, NTW = NT / CS, TB = WAVES * 64, NI = 4 / CS;
-  static_assert(WAVES == 4 || (WAVES == 8 && NT % 2 == 0), "8 waves split the column tiles in two");
-  const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5, wv = (threadIdx.x >> 6) & 3, wc = threadIdx.x >> 8;
-  const long long r0 = (long long)blockIdx.x * rows_per_block;
-  const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  const int nx = 32 * K, ng = 32 * N, per_buf = nx + ng;
-  const int nslab = r1 > r0 ? (int)((r1 - r0 + 31) / 32) : 0;
-
-  // staging registers: up to 4 float4 (or 16 floats) of x, of dy and of y per thread (K, N <= 128)
-  float xr[NI][4], gr[NI][4], yr[NI][4];
-  auto fetch = [&](int s) {
-    const long long m0 = r0 + 32LL * s;
-    const long long left = r1 - m0;  // rows of this slab inside the block's range
-    const float* xs = x + (size_t)m0 * K;
-    const float* gs = dy + (size_t)m0 * N;
-    const float* ys = DACT ? yout + (size_t)m0 * N : nullptr;
-    const long long xe = (left < 32 ? left : 32) * K, ge = (left < 32 ? left : 32) * N;  // valid elements
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int e = 4 * (threadIdx.x + TB * i);
-      if (e < nx) {
-        if (xvec_ok && e + 4 <= xe) {
-          const f4v t = *reinterpret_cast<const f4v*>(xs + e);
-          xr[i][0] = t[0]; xr[i][1] = t[1]; xr[i][2] = t[2]; xr[i][3] = t[3];
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) xr[i][q] = (e + q < xe) ? xs[e + q] : 0.f;
-        }
-      }
-      if (e < ng) {
-        if (gvec_ok && e + 4 <= ge) {
-          const f4v t = *reinterpret_cast<const f4v*>(gs + e);
-          gr[i][0] = t[0]; gr[i][1] = t[1]; gr[i][2] = t[2]; gr[i][3] = t[3];
-          if (DACT) {
-            const f4v u = *reinterpret_cast<const f4v*>(ys + e);
-            yr[i][0] = u[0]; yr[i][1] = u[1]; yr[i][2] = u[2]; yr[i][3] = u[3];
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            gr[i][q] = (e + q < ge) ? gs[e + q] : 0.f;
-            if (DACT) yr[i][q] = (e + q < ge) ? ys[e + q] : 0.f;
-          }
-        }
-      }
-    }
-  };
-  auto stage = [&](int buf) {
-    float* xs = slab + (size_t)buf * per_buf;
-    float* gs = xs + nx;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int e = 4 * (threadIdx.x + TB * i);
-      if (e < nx) {  // nx and ng are multiples of 32: whole float4
-        const f4v t = {xr[i][0], xr[i][1], xr[i][2], xr[i][3]};
-        *reinterpret_cast<f4v*>(xs + e) = t;
-      }
-      if (e < ng) {
-        f4v t = {gr[i][0], gr[i][1], gr[i][2], gr[i][3]};
-        if (DACT) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) t[q] *= 1.f - yr[i][q] * yr[i][q];
-        }
-        *reinterpret_cast<f4v*>(gs + e) = t;
-      }
-    }
-  };
-
-  f16v acc[KPW][NTW];
-#pragma unroll
-  for (int p = 0; p < KPW; ++p)
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[p][j][r] = 0.f;
-  // this lane's row of P per k-tile: a column of x, the row of ones (bias) or nothing
-  int kx[KPW], kmode[KPW];  // mode 0: read x, 1: ones, 2: zero
-#pragma unroll
-  for (int p = 0; p < KPW; ++p) {
-    const int k = 32 * (wv + 4 * p) + l32;
-    kmode[p] = (wv + 4 * p >= KT) ? 2 : k < K ? 0 : k == K ? 1 : 2;
-    kx[p] = k < K ? k : 0;
-  }
-  int ncol[NTW];
-  bool nok[NTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    const int n = 32 * (wc * NTW + j) + l32;
-    nok[j] = n < N;
-    ncol[j] = nok[j] ? n : 0;
-  }
-
-  if (nslab > 0) {
-    fetch(0);
-    stage(0);
-  }
-  __syncthreads();
-  for (int s = 0; s < nslab; ++s) {
-    if (s + 1 < nslab) fetch(s + 1);
-    const float* xs = slab + (size_t)(s & 1) * per_buf;
-    const float* gs = xs + nx;
-    if (wv < KT) {  // (a block's waves beyond the k-tiles only help with the copies)
-#pragma unroll 4
-      for (int st = 0; st < 16; ++st) {
-        const int m = 2 * st + h;
-        float bv[NTW];
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-          const float t = gs[m * N + ncol[j]];
-          bv[j] = nok[j] ? t : 0.f;
-        }
-#pragma unroll
-        for (int p = 0; p < KPW; ++p) {
-          const float t = xs[m * K + kx[p]];
-          const float a = kmode[p] == 0 ? t : kmode[p] == 1 ? 1.f : 0.f;
-#pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[p][j], 0, 0, 0);
-        }
-      }
-    }
-    if (s + 1 < nslab) stage((s + 1) & 1);
-    __syncthreads();
-  }
-  float* out = partial + (size_t)blockIdx.x * (32 * KT) * Np;
-#pragma unroll
-  for (int p = 0; p < KPW; ++p) {
-    const int kt = wv + 4 * p;
-    if (kt >= KT) continue;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float* o = out + (size_t)(32 * kt + mm_row(r, lane)) * Np + 32 * wc * NTW + l32;
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) o[32 * j] = acc[p][j][r];
-    }
-  }
-}
-
+// P[K][n] = sum_m G(m,n) (bias), G = dy or, with DACT, dy * (1 - y^2).  partial: [gridDim.x][32 * KT][32 * NT].
+//
 // The weight gradient without LDS staging.  Which row of P an accumulator row stands for, and which column an
 // accumulator column, is free: with KV accumulators down and NV across, row r of accumulator i is k = KV*r + i and
 // column c of accumulator j is n = NV*CS*c + NV*cs + j (cs = the wave's column share when 128 columns are split
@@ -705,7 +506,6 @@ int rnnt_mi355x_dense_backward(const float* x, const float* w, const float* y, c
     const int nt = nt_for(N), KT = (K + 1 + 31) / 32;
     int nb = wgrad_blocks(M);
     float* partial = static_cast<float*>(workspace);
-#ifndef RNNT_WGRAD_LDS
     {
       const int kv = K <= 32 ? 1 : K <= 64 ? 2 : 4, nv = nt >= 2 ? 2 : 1, cs = nt == 4 ? 2 : 1;
       const bool al = (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
@@ -748,56 +548,6 @@ int rnnt_mi355x_dense_backward(const float* x, const float* w, const float* y, c
 #undef DENSE_WGRAD_DIRECT3
       if (r != RNNT_MI355X_OK) return r;
     }
-#elif !defined(RNNT_DENSE_WGRAD_OLD)
-    {
-      // operands staged through LDS; a persistent grid of at most one resident round of blocks
-      const size_t lds = sizeof(float) * 2 * 32 * (size_t)(K + N);
-      const bool xv = reinterpret_cast<uintptr_t>(x) % 16 == 0;
-      const bool gv4 = reinterpret_cast<uintptr_t>(dy) % 16 == 0 && (act == 0 || reinterpret_cast<uintptr_t>(y) % 16 == 0);
-      long long rows = 0;
-      auto go = [&](auto kern, int threads) -> int {
-        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-          return RNNT_MI355X_LAUNCH_FAILURE;
-        int per_cu = 0, dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-          cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        if ((long long)per_cu * cus < nb) nb = per_cu * cus;
-        rows = (M + nb - 1) / nb;
-        rows = (rows + 31) & ~31LL;
-        nb = (int)((M + rows - 1) / rows);
-        kern<<<nb, threads, lds, st>>>(x, y, dy, partial, M, K, N, KT, rows, xv, gv4);
-        return RNNT_MI355X_OK;
-      };
-      int r = RNNT_MI355X_OK;
-#define DENSE_WGRAD_LDS(NT)                                                             \
-  do {                                                                                  \
-    constexpr int WV = (NT) >= 2 ? RNNT_WGRAD_WAVES : 4;                                  \
-    if (KT > 4) r = act == 1 ? go(k_dense_wgrad_lds<NT, true, 2, WV>, 64 * WV) : go(k_dense_wgrad_lds<NT, false, 2, WV>, 64 * WV); \
-    else r = act == 1 ? go(k_dense_wgrad_lds<NT, true, 1, WV>, 64 * WV) : go(k_dense_wgrad_lds<NT, false, 1, WV>, 64 * WV);        \
-  } while (0)
-      if (nt == 1) DENSE_WGRAD_LDS(1);
-      else if (nt == 2) DENSE_WGRAD_LDS(2);
-      else DENSE_WGRAD_LDS(4);
-#undef DENSE_WGRAD_LDS
-      if (r != RNNT_MI355X_OK) return r;
-    }
-#else
-    const bool gv = nvec_ok(dy, N, nt) && (act == 0 || nvec_ok(y, N, nt));
-    long long rows = (M + nb - 1) / nb;
-    rows = (rows + 7) & ~7LL;
-#define DENSE_WGRAD(NT)                                                                                          \
-  do {                                                                                                           \
-    if (act == 1) k_dense_wgrad<NT, true><<<nb, kBlock, 0, st>>>(x, y, dy, partial, M, K, N, KT, rows, gv);       \
-    else k_dense_wgrad<NT, false><<<nb, kBlock, 0, st>>>(x, y, dy, partial, M, K, N, KT, rows, gv);               \
-  } while (0)
-    if (nt == 1) DENSE_WGRAD(1);
-    else if (nt == 2) DENSE_WGRAD(2);
-    else DENSE_WGRAD(4);
-#undef DENSE_WGRAD
-#endif
     const int total = (K + 1) * N * 16;
     k_dense_wgrad_reduce<<<(total + kBlock - 1) / kBlock, kBlock, 0, st>>>(partial, dw, db, K, N, 32 * KT, 32 * nt, nb);
   }

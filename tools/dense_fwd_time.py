@@ -13,11 +13,12 @@ for name in sys.argv[1:]:
         y = torch.empty(M, N, device=dev)
         f = L.rnnt_mi355x_dense_forward
         f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-        for _ in range(3): assert f(p(x), p(w), p(b), M, K, N, 1, p(y), None) == 0
+        ACT = int(os.environ.get("ACT", "1"))
+        for _ in range(3): assert f(p(x), p(w), p(b), M, K, N, ACT, p(y), None) == 0
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10): f(p(x), p(w), p(b), M, K, N, 1, p(y), None)
+        for _ in range(10): f(p(x), p(w), p(b), M, K, N, ACT, p(y), None)
         e1.record(); torch.cuda.synchronize()
         out.append(f"K={K} N={N}: {e0.elapsed_time(e1) / 10 * 1e3:.0f} us")
     print(f"{name:10s}", " | ".join(out), flush=True)
