@@ -124,7 +124,10 @@ def test_fc_joint_equals_dense_stack_on_the_tiled_tensor():
 
 # M, K, N: the reference sample's last layer (100 -> 62), widths that are not multiples of anything, the limits,
 # a single row, many row tiles with a ragged tail
-DENSE_SHAPES = [(1000, 100, 62), (77, 7, 5), (4097, 128, 128), (1, 3, 2), (333, 33, 100), (50000, 100, 62), (260, 64, 32)]
+DENSE_SHAPES = [(1000, 100, 62), (77, 7, 5), (4097, 128, 128), (1, 3, 2), (333, 33, 100), (50000, 100, 62), (260, 64, 32),
+                # the weight gradient's other forms: odd widths above 64 (element-wise loads, four accumulators down),
+                # two accumulators down and two across, 128 columns split over two waves with an odd K
+                (500, 99, 50), (3000, 64, 40), (129, 127, 65), (2, 100, 62)]
 
 
 @pytest.mark.parametrize("M,K,N", DENSE_SHAPES)
