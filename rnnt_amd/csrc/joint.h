@@ -458,33 +458,41 @@ __device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   auto b_off = [&](int k0, int i) { return ((size_t)(k0 >> 5) * chunks << 8) + (((k0 & 31) + i) << 3); };
-  // Two register sets used alternately: the loads of one are in flight during the 4*NT MFMAs of the other.
-  f4v a0, a1;
-  vecn bv0[4], bv1[4];
-  auto load_set = [&](int k0, f4v& a, vecn (&bv)[4]) {
-    a = ld4(ap + ((size_t)(k0 >> 3) << 8));
+  // A ring of D register sets (8 columns of A and 8 rows of Bm each): a set is re-loaded right after the 4*NT MFMAs
+  // that consumed it, so its loads have the MFMAs of the other D-1 sets to come back.  (Written as "load the next
+  // set, then multiply this one" with two sets, the compiler moved the loads below the MFMAs they were meant to
+  // overlap; a load that follows the last use of its own registers cannot be moved up, and the scheduling barrier
+  // keeps it from moving down.)
+#ifndef RNNT_JOINT_RING
+#define RNNT_JOINT_RING 3
+#endif
+  constexpr int D = (NT == 4 && CORR) ? 2 : RNNT_JOINT_RING;  // (the epilogue of that form needs the registers)
+  f4v a[D];
+  vecn bv[D][4];
+  auto load_set = [&](int k0, f4v& av, vecn (&bw)[4]) {
+    av = ld4(ap + ((size_t)(k0 >> 3) << 8));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const vecn*>(bp + b_off(k0, i));
+    for (int i = 0; i < 4; ++i) bw[i] = *reinterpret_cast<const vecn*>(bp + b_off(k0, i));
   };
-  auto mfma_set = [&](const f4v& a, const vecn (&bv)[4]) {
+  auto mfma_set = [&](const f4v& av, const vecn (&bw)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], fvec_get<NT>(bv[i], j), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], fvec_get<NT>(bw[i], j), acc[j], 0, 0, 0);
   };
   if (kmax > kbeg) {  // K range [kbeg, kmax), both multiples of 8
-    load_set(kbeg, a0, bv0);
-    for (int k0 = kbeg; k0 < kmax; k0 += 16) {
-      const bool second = k0 + 8 < kmax;  // uniform
-      load_set(second ? k0 + 8 : k0, a1, bv1);
+    const int klast = kmax - 8;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      load_set(min(kbeg + 8 * d, klast), a[d], bv[d]);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_set(a0, bv0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (second) {
-        load_set(min(k0 + 16, kmax - 8), a0, bv0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_set(a1, bv1);
+    }
+    for (int k0 = kbeg; k0 < kmax; k0 += 8 * D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (k0 + 8 * d < kmax) mfma_set(a[d], bv[d]);  // uniform
+        load_set(min(k0 + 8 * (d + D), klast), a[d], bv[d]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -574,8 +582,10 @@ __device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, 
 // d f(t,v) = F(t,v) * sum_u C(t,u) G(u,v): M = frames, N = vocabulary, K = label positions.
 // CORR: the blank / label terms are subtracted in the epilogue (k_joint_labelmap has run); otherwise
 // k_joint_corr_f follows.
+// (compiled for two resident waves per SIMD: the epilogue with the label chains came to 194 + 64 registers, two more
+// than that allows, and ran one wave per SIMD)
 template <int NT, bool CORR>
-__global__ __launch_bounds__(256) void k_joint_df_mm(float* __restrict__ df, const int32_t* __restrict__ in_len,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_joint_df_mm(float* __restrict__ df, const int32_t* __restrict__ in_len,
                                                      const int32_t* __restrict__ lab_len, JointGeom jg, Ws w,
                                                      bool vec_ok) {
   const MmTile mt = mm_tile(jg.B, w.Tp / 32, w.Vp / (32 * NT), 32 * NT);
@@ -599,7 +609,7 @@ __global__ __launch_bounds__(256) void k_joint_df_mm(float* __restrict__ df, con
 // the frames are cut into that many slices, each wavefront tile takes one slice and writes its partial result to
 // w.dgpart; k_joint_corr_g adds the slices up.
 template <int NT>
-__global__ __launch_bounds__(256) void k_joint_dg_mm(float* __restrict__ dg, const int32_t* __restrict__ in_len,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_joint_dg_mm(float* __restrict__ dg, const int32_t* __restrict__ in_len,
                                                      const int32_t* __restrict__ lab_len, JointGeom jg, Ws w,
                                                      bool vec_ok) {
   const int ks = w.dg_split;
