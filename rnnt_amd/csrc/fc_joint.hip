@@ -239,7 +239,13 @@ __global__ __launch_bounds__(kBlock) void k_fcj_bwd(const float* __restrict__ pe
 // partial as in k_fcj_bwd); only the G partial sums per (frame, column) go through LDS, once, at the end of the
 // block, and are added in order of g (fixed summation order).  Label positions are walked in tiles of G * NG rows.
 template <int NG>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_fcj_bwd_cols(const float* __restrict__ pe, const float* __restrict__ pd,
+#ifndef RNNT_FCJ_WPE
+#define RNNT_FCJ_WPE 3
+#endif
+#ifndef RNNT_FCJ_DEPTH  // frames whose loads are in flight ahead of the one being worked on, + 1
+#define RNNT_FCJ_DEPTH 2
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RNNT_FCJ_WPE))) void k_fcj_bwd_cols(const float* __restrict__ pe, const float* __restrict__ pd,
                                                          const float* __restrict__ dh, float* __restrict__ dpe,
                                                          float* __restrict__ partial, int T, int U1, int H,
                                                          int nchunk) {
@@ -262,30 +268,36 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
 #pragma unroll
   for (int tt = 0; tt < kFrames; ++tt) su[tt] = f4v{0.f, 0.f, 0.f, 0.f};
   for (int u0 = 0; u0 < U1; u0 += G * NG) {
+    // every load is unconditional (rows past U1 and frames past nt re-read the last ones; what they produce is
+    // dropped at use): no divergent branch around the loads, so the waits for them can be counted
     f4v pdv[NG], acc[NG];
     bool ok[NG];
+    unsigned roff[NG];
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
       const int u = u0 + k * G + g;
       ok[k] = on && u < U1;
+      roff[k] = (unsigned)min(u, U1 - 1) * (unsigned)H;
       acc[k] = f4v{0.f, 0.f, 0.f, 0.f};
-      pdv[k] = ok[k] ? *reinterpret_cast<const f4v*>(pdb + (size_t)u * H) : f4v{0.f, 0.f, 0.f, 0.f};
+      pdv[k] = *reinterpret_cast<const f4v*>(pdb + roff[k]);
     }
     // the loads of frame tt + 1 are in flight while frame tt is worked on (two register sets; the scheduling
     // barriers keep the compiler from hoisting more frames than that: all eight would cost a resident block)
-    f4v dv[2][NG];
+    constexpr int FD = RNNT_FCJ_DEPTH;
+    f4v dv[FD][NG];
     auto fetch = [&](int tt, f4v (&d)[NG]) {
-      const float* src = dhb + (size_t)tt * U1 * H;
+      const float* src = dhb + (size_t)min(tt, nt - 1) * U1 * H;
 #pragma unroll
-      for (int k = 0; k < NG; ++k)
-        d[k] = (ok[k] && tt < nt)
-                   ? __builtin_nontemporal_load(reinterpret_cast<const f4v*>(src + (size_t)(u0 + k * G + g) * H))
-                   : f4v{0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < NG; ++k) d[k] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(src + roff[k]));
     };
-    fetch(0, dv[0]);
+#pragma unroll
+    for (int tt = 0; tt < FD - 1; ++tt) {
+      fetch(tt, dv[tt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int tt = 0; tt < kFrames; ++tt) {
-      if (tt + 1 < kFrames) fetch(tt + 1, dv[(tt + 1) & 1]);
+      if (tt + FD - 1 < kFrames) fetch(tt + FD - 1, dv[(tt + FD - 1) % FD]);
       __builtin_amdgcn_sched_barrier(0);
       if (tt < nt) {  // uniform
         const f4v pev = *reinterpret_cast<const f4v*>(pe_s + tt * H + 4 * hc);
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float hh = tanh_fast(pev[e] + pdv[k][e]);
-            const float d = dv[tt & 1][k][e] * __builtin_fmaf(-hh, hh, 1.f);
+            const float d = ok[k] ? dv[tt % FD][k][e] * __builtin_fmaf(-hh, hh, 1.f) : 0.f;
             acc[k][e] += d;
             su[tt][e] += d;
           }
