@@ -142,61 +142,80 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
     return in_range & (t < T) & (u <= U);
   };
 
+  // Every pass issues the same NLD loads: a tile without a lattice cell is not skipped but replaced by a re-read of
+  // the last tile this wave did load (its own, recent addresses: served by the caches, and no address that every
+  // wave would hit at once), and the lanes past the end of a tile re-read its last 16 bytes.  With conditional loads
+  // the compiler cannot count what is outstanding.
   f4v st[NLD];
+  int n_read = gw < g.ntiles_full ? gw : 0;
   auto issue = [&](int n, bool any) {
-    if (!any) return;
-    const f4v* src = x4 + (size_t)n * tile_f4;
+    n_read = any ? n : n_read;
+    const f4v* src = x4 + (size_t)n_read * tile_f4;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int q = lane + 64 * i;
-      if (q < tile_f4) st[i] = __builtin_nontemporal_load(src + q);
-    }
+    for (int i = 0; i < NLD; ++i) st[i] = __builtin_nontemporal_load(src + min(lane + 64 * i, tile_f4 - 1));
   };
 
+  // The counter that memory operations are waited on is in-order: a wait for one load also waits for everything
+  // issued before it, and a wait the compiler cannot count (conditional stores in flight) waits for everything.
+  // So nothing in the loop waits except its top, and what is outstanding there is what it needs: a tile's label is
+  // loaded ahead of its logits, at decode time, and a tile's record is stored one pass later, after the next tile
+  // has been staged and before the loads of the one after go out (a label looked up after the row's sum, and the
+  // records stored at the end of the pass, made every pass wait twice for loads it had only just issued).
   int n = gw;
-  int b = -1, t = 0, u = 0, U = 0;
+  int b = -1, t = 0, u = 0, U = 0, lab = 0;
   bool in_range = false;
   bool valid = false, any = false;
+  auto label_of = [&](bool ok, int bb, int uu, int UU) {
+    return (ok && uu < UU) ? labels[(size_t)bb * (g.maxU1 - 1) + uu] : 0;
+  };
   if (n < g.ntiles_full) {
     valid = row_valid(n, b, t, u, U, in_range);
     any = __ballot(valid) != 0ull;
+    lab = label_of(valid, b, u, U);
     issue(n, any);
   }
+  int pb = 0, pt = 0, pu = 0;  // the previous tile's row and record, not stored yet
+  bool pin = false;
+  float4 prc = make_float4(kNegF, kNegF, 0.f, 0.f);
   for (; n < g.ntiles_full; n += nw) {
     // stage the tile into LDS (only this wavefront touches it: in-order LDS, no barrier needed)
-    if (any) {
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int q = lane + 64 * i;
-        if (q < tile_f4) tile4[slot(q)] = make_float4(st[i].x, st[i].y, st[i].z, st[i].w);
-      }
+    for (int i = 0; i < NLD; ++i) {
+      const int q = min(lane + 64 * i, tile_f4 - 1);
+      tile4[slot(q)] = make_float4(st[i].x, st[i].y, st[i].z, st[i].w);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (pin) small_write_record(w, g, pb, pt, pu, prc);
+    __builtin_amdgcn_sched_barrier(0);
     const int cb = b, ct = t, cu = u, cU = U;
+    int clab = lab;
     const bool cvalid = valid, cany = any, cin = in_range;
     // next tile: decode and put its loads in flight before working on this one
     const int nn = n + nw;
     if (nn < g.ntiles_full) {
       valid = row_valid(nn, b, t, u, U, in_range);
       any = __ballot(valid) != 0ull;
+      lab = label_of(valid, b, u, U);
       issue(nn, any);
     }
+    __builtin_amdgcn_sched_barrier(0);
     float4 rc = make_float4(kNegF, kNegF, 0.f, 0.f);
     if (cany && cvalid) {
       float m2, ls;
       small_row_lse2<VEC>(rowp, V, m2, ls);
       float lpl = kNegF;
       if (cu < cU) {
-        int lab = labels[(size_t)cb * (g.maxU1 - 1) + cu];
-        if (lab < 0 || lab >= V) {
+        if (clab < 0 || clab >= V) {
           atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
-          lab = 0;
+          clab = 0;
         }
-        lpl = __builtin_fmaf(rowp[lab], kLog2e, -m2) - ls;
+        lpl = __builtin_fmaf(rowp[clab], kLog2e, -m2) - ls;
       }
       rc = make_float4(__builtin_fmaf(rowp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, 0.f);
     }
-    if (cin) small_write_record(w, g, cb, ct, cu, rc);
+    pb = cb; pt = ct; pu = cu; pin = cin; prc = rc;
   }
+  if (pin) small_write_record(w, g, pb, pt, pu, prc);
   // the last, partial tile (fewer than 64 rows): one wavefront reads its rows straight from global memory
   if (gw == 0 && (long long)g.ntiles_full * 64 < g.total_rows) {
     const long long row = (long long)g.ntiles_full * 64 + lane;
