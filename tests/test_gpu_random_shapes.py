@@ -21,7 +21,7 @@ GRAD_ATOL = 1e-4
 # 1 + tiny, good to one ulp of 1 (6e-8) whatever the implementation, and the logits of such a row are large, so the
 # cost carries a few 1e-7 absolute: the relative bar needs a floor there.
 COST_ATOL = 1e-6
-SUM_RTOL = 3e-5  # d f / d g of the fused joint: sums of up to hundreds of joint-gradient elements
+SUM_RTOL = 6e-5  # d f / d g of the fused joint: sums of up to hundreds of joint-gradient elements (the bar is 1e-4)
 SCALES = (0.3, 1.0, 3.0, 6.0)  # standard deviations the logits are drawn with
 MAX_T, MAX_U1, SIZE_FACTOR = 150, 330, 1  # the soak script raises these
 
@@ -112,7 +112,8 @@ def test_random_additive_joints(seed):
                                err_msg=str((B, T, U, V, blank, scale)))
     # d f sums the joint gradient over u, d g over t: up to U+1 (T) terms, each within the bar.  With a symbol repeated
     # a hundred times an element is the difference of two sums of a hundred or more (occupancy times softmax, and
-    # the label terms), each accumulated in float32: hence the relative term.  Worst seen in 10^4 draws: 2.3e-5.
+    # the label terms), each accumulated in float32: hence the relative term.  Worst seen in 1.3 * 10^4 draws: 4.9e-5
+    # (seed 270381: U = 319, two symbols, logits ~ 6 N(0,1): an element of 16.4 that is the difference of two sums near 55).
     np.testing.assert_allclose(tf_.grad.cpu().numpy(), gj.sum(2), atol=GRAD_ATOL, rtol=SUM_RTOL,
                                err_msg=str((B, T, U, V, blank, scale)))
     np.testing.assert_allclose(tg.grad.cpu().numpy(), gj.sum(1), atol=GRAD_ATOL, rtol=SUM_RTOL,
