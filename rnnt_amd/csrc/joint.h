@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_joint_lse_mm(const float* __restrict__ 
   float fbv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) fbv[r] = fbl[min(t0 + mm_row(r, lane), T - 1)];
-  unsigned badmask = 0;
+  unsigned long long badmask = 0;  // bit 16*j + r
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int u = u0 + 32 * j + l32;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_joint_lse_mm(const float* __restrict__ 
       const bool valid = t < T && u <= U;
       const float S = acc[j][r];
       const bool bad = valid && !(S >= kJointMinSum);
-      badmask |= bad ? (1u << (16 * j + r)) : 0u;
+      badmask |= bad ? (1ull << (16 * j + r)) : 0ull;
       if (valid && !bad) {
         const float ls = fast_log2(S);
         frame0[(size_t)t * jg.maxU1 + u] =
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void k_joint_lse_mm(const float* __restrict__ 
     for (int q = 0; q < 16 * NT; ++q) {
       const int j = q >> 4, r = q & 15;
       const int t = t0 + mm_row(r, lane), u = u0 + 32 * j + l32;
-      const bool bad = (badmask >> q) & 1u;
+      const bool bad = (badmask >> q) & 1ull;
       unsigned long long m = __ballot(bad);
       float ls = 0.f;
       while (m) {

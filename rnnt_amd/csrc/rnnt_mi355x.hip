@@ -524,6 +524,10 @@ int launch_joint_forward(const JointCall& c, float* costs, hipStream_t st) {
   const int mt = w.Tp / 32;
   if (w.U1p <= 32)
     k_joint_lse_mm<1><<<mm_blocks(jg.B, mt, 1), 256, 0, st>>>(c.f, c.g, c.in_len, c.lab_len, jg, w);
+  // strips of 128 label positions where the sum over the vocabulary is long: fewer operand loads per MFMA (T=400,
+  // U+1=101, V=1024: 89 -> 83 us; at V=62, where a wave's whole sum is 4 steps, the halved wave count loses: 12.7 -> 16.6 us)
+  else if (w.U1p > 64 && w.Vp >= 256)
+    k_joint_lse_mm<4><<<mm_blocks(jg.B, mt, (w.U1p + 127) / 128), 256, 0, st>>>(c.f, c.g, c.in_len, c.lab_len, jg, w);
   else
     k_joint_lse_mm<2><<<mm_blocks(jg.B, mt, (w.U1p + 63) / 64), 256, 0, st>>>(c.f, c.g, c.in_len, c.lab_len, jg, w);
   Call sc;  // the lattice sweep is the one of the materialised path
