@@ -275,6 +275,13 @@ void launch_lse(const Call& c, int b0, int nb, hipStream_t st) {
 
 void launch_sweep(const Call& c, int b0, int nb, hipStream_t st) {
   const int grid = 2 * nb;
+  if (sweep_is_wide(c.maxU1)) {  // (whole batch only: the re-ordered records are built for all of it)
+    const int tpb = c.w.U1s < 256 ? c.w.U1s : 256;
+    k_skew_records<<<dim3((unsigned)(c.w.U1s / tpb), (unsigned)(c.w.Dp / kSkewRows), (unsigned)c.B), tpb, 0, st>>>(
+        c.w, c.maxT, c.maxU1);
+    k_sweep_wide<<<grid, 64 * ((c.maxU1 + 63) / 64), 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0);
+    return;
+  }
   switch (sweep_cols_per_lane(c.maxU1)) {
     case 1: k_sweep<1><<<grid, 64, 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0); break;
     case 2: k_sweep<2><<<grid, 64, 0, st>>>(c.w, c.costs, c.in_len, c.lab_len, c.B, c.maxT, c.maxU1, b0); break;

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "workspace.h"
 #include "device_util.h"
 
@@ -236,6 +238,176 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
       }
     }
     if (lane == 0) w.ll[B + b] = bt[0];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Lattices with more than 128 label positions.  With 4, 8 or 16 columns per lane a diagonal of k_sweep costs
+// 245 / 490 / 1000 ns: the columns of a lane are worked on one after the other.  Here a block has one wavefront
+// per 64 columns, each at the one-column pace, and the two things that made that slow before are gone:
+//  * k_skew_records first re-orders the log-probs by anti-diagonal (and writes "log 0" wherever a diagonal has no
+//    cell), so a wavefront's 64 cells of a diagonal are 512 contiguous bytes instead of 64 cache lines -- the
+//    compute unit's vector cache takes a line per cycle whichever wavefront asks;
+//  * the one number per diagonal that a wavefront needs from its neighbour goes through LDS in bands of
+//    kSweepBand diagonals, and the wavefronts run one band apart (rank r works on band s - r in pass s), so a
+//    band's values were all written in the pass before: one block barrier per band, nothing is polled.
+// ---------------------------------------------------------------------------
+// grid (U1s / 256 or 1, Dp / kSkewRows, B), blocks of min(U1s, 256) threads: a thread fills column u of kSkewRows
+// diagonals (one diagonal per block is a launch of 10^5 blocks of a few instructions each: dispatch-bound)
+constexpr int kSkewRows = 16;  // divides kSweepBand, hence Dp
+__global__ __launch_bounds__(256) void k_skew_records(Ws w, int maxT, int maxU1) {
+  const int U1s = w.U1s;
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
+  const int d0 = blockIdx.y * kSkewRows;
+  const float4* rb = w.rec + ((size_t)b * (maxT + 2) + 1) * maxU1 + u;
+  float2 v[kSkewRows];
+#pragma unroll
+  for (int i = 0; i < kSkewRows; ++i) {  // all the loads first
+    const int t = d0 + i - u;
+    v[i] = make_float2(kNegF, kNegF);
+    if (u < maxU1 && t >= 0 && t < maxT) v[i] = *reinterpret_cast<const float2*>(rb + (size_t)t * maxU1);
+  }
+  float2* out = w.lp2 + ((size_t)b * w.Dp + d0) * U1s + u;
+#pragma unroll
+  for (int i = 0; i < kSkewRows; ++i) out[(size_t)i * U1s] = v[i];
+}
+
+__global__ __launch_bounds__(1024) void k_sweep_wide(Ws w, float* __restrict__ costs, const int32_t* __restrict__ in_len,
+                                                     const int32_t* __restrict__ lab_len, int B, int maxT, int maxU1,
+                                                     int b0) {
+  constexpr int P = 16, DB = kSweepBand;
+  static_assert(DB % P == 0 && DB <= 64 && DB % kSkewRows == 0, "a band is whole groups of the ring and fits one lane per diagonal");
+  __shared__ double hand[16][2][DB];  // [boundary between rank r and r + 1][band parity][diagonal of the band]
+  const int W = (int)(blockDim.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int b = b0 + (blockIdx.x >> 1);
+  const int dir = blockIdx.x & 1;
+  const int Traw = in_len[b], Uraw = lab_len[b];
+  const bool ok = (Traw >= 1) & (Traw <= maxT) & (Uraw >= 0) & (Uraw <= maxU1 - 1);
+  if (!ok) {  // the whole block leaves, before any barrier
+    if (threadIdx.x == 0) {
+      atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LENGTH);
+      w.ll[dir * B + b] = 0.0;
+      if (dir == 0) costs[b] = __builtin_nanf("");
+    }
+    return;
+  }
+  const int T = Traw, U = Uraw;
+  const unsigned U1s = (unsigned)w.U1s;
+  const size_t plane = (size_t)b * w.D * U1s;
+  const int u = 64 * wv + lane;  // < U1s: the block has ceil(maxU1 / 64) wavefronts
+  const int dlast = T - 1 + U;
+  const float2* lp = w.lp2 + (size_t)b * w.Dp * U1s + u;
+  const int rowmax = w.Dp - 1;
+  const int rank = dir == 0 ? wv : W - 1 - wv;  // the wavefront that leads owns the columns the recursion starts in
+  float pb[P], pl[P];
+  auto load_lp = [&](int d, float& b_, float& l_) {
+    const float2 q = lp[(size_t)min(max(d, 0), rowmax) * U1s];
+    b_ = q.x;
+    l_ = q.y;
+  };
+
+  if (dir == 0) {
+    double* alpha = w.alpha + plane + u;
+    double a = (u == 0) ? 0.0 : kNeg;
+    alpha[0] = a;
+    const int nbands = (dlast + DB - 1) / DB;  // diagonals 1 .. dlast
+    const int nsteps = nbands + W - 1;
+    // the ring: diagonal d needs the log-probs of diagonal d - 1
+    if (nbands > 0) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) load_lp(p, pb[p], pl[p]);
+    }
+    for (int s = 0; s < nsteps; ++s) {
+      const int j = s - rank;
+      if (j >= 0 && j < nbands) {  // uniform in the wavefront
+        const int d0 = 1 + j * DB;
+        // the neighbour's hand-over values of this band (written in the pass before): lane i holds diagonal d0 + i
+        double hin = kNeg;
+        if (rank > 0 && lane < DB) hin = hand[rank - 1][j & 1][lane];
+        {  // waited for here, once: otherwise every diagonal's first use waits for LDS, its own hand-over write included
+          int hlo = __double2loint(hin), hhi = __double2hiint(hin);
+          asm volatile("" : "+v"(hlo), "+v"(hhi));
+          hin = __hiloint2double(hhi, hlo);
+        }
+        double* hout = hand[rank][j & 1];
+        // A band that lies wholly inside the lattice runs without a branch (every pass the same loads and stores:
+        // the waits for the ring are counted); only an utterance's last, partial band tests each diagonal.
+        auto band = [&](auto whole) {
+#pragma unroll
+          for (int g = 0; g < DB; g += P) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              const int d = d0 + g + p;
+              if (decltype(whole)::value || d <= dlast) {  // uniform
+                const double el = a + (double)pl[p];
+                if (lane == 63) hout[g + p] = el;
+                const double fill = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hin), g + p),
+                                                     __builtin_amdgcn_readlane(__double2loint(hin), g + p));
+                const double from_left = lane_shift_up(el, fill);
+                a = log2_add(a + (double)pb[p], from_left);
+                alpha[(size_t)d * U1s] = a;
+              }
+              load_lp(d - 1 + P, pb[p], pl[p]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        };
+        if (d0 + DB - 1 <= dlast) band(std::true_type{});
+        else band(std::false_type{});
+      }
+      __syncthreads();
+    }
+    if (u == U) {
+      const double ll2 = a + (double)w.rec[((size_t)b * (maxT + 2) + T) * maxU1 + U].x;  // frame T-1 is at index T
+      w.ll[b] = ll2;
+      costs[b] = (float)(-ll2 * kLn2);
+    }
+  } else {
+    double* beta = w.beta + plane + u;
+    double bt = (u == U) ? 0.0 : kNeg;  // virtual diagonal dlast + 1
+    const int nbands = (dlast + 1 + DB - 1) / DB;  // diagonals dlast .. 0
+    const int nsteps = nbands + W - 1;
+#pragma unroll
+    for (int p = 0; p < P; ++p) load_lp(dlast - p, pb[p], pl[p]);
+    for (int s = 0; s < nsteps; ++s) {
+      const int j = s - rank;
+      if (j >= 0 && j < nbands) {
+        const int d0 = dlast - j * DB;
+        double hin = kNeg;
+        if (rank > 0 && lane < DB) hin = hand[rank - 1][j & 1][lane];
+        {  // waited for here, once: otherwise every diagonal's first use waits for LDS, its own hand-over write included
+          int hlo = __double2loint(hin), hhi = __double2hiint(hin);
+          asm volatile("" : "+v"(hlo), "+v"(hhi));
+          hin = __hiloint2double(hhi, hlo);
+        }
+        double* hout = hand[rank][j & 1];
+        auto band = [&](auto whole) {
+#pragma unroll
+          for (int g = 0; g < DB; g += P) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              const int d = d0 - g - p;
+              if (decltype(whole)::value || d >= 0) {  // uniform
+                if (lane == 0) hout[g + p] = bt;
+                const double fill = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hin), g + p),
+                                                     __builtin_amdgcn_readlane(__double2loint(hin), g + p));
+                const double from_right = lane_shift_down(bt, fill);
+                bt = log2_add(bt + (double)pb[p], from_right + (double)pl[p]);
+                beta[(size_t)d * U1s] = bt;
+              }
+              load_lp(d - P, pb[p], pl[p]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        };
+        if (d0 - (DB - 1) >= 0) band(std::true_type{});
+        else band(std::false_type{});
+      }
+      __syncthreads();
+    }
+    if (u == 0) w.ll[B + b] = bt;
   }
 }
 

@@ -48,6 +48,11 @@ struct Ws {
   float4* rec;
   double* alpha;   // [B][D][U1s]
   double* beta;    // [B][D][U1s]
+  // more than 128 label positions only: {log2 P(blank), log2 P(label)} of the cell (d - u, u) at [B][Dp][U1s], "log 0"
+  // where there is no such cell -- the records by anti-diagonal, so that a wavefront of the wide sweep reads the 64
+  // cells of a diagonal it owns as one contiguous run
+  float2* lp2;
+  int Dp;          // rows of lp2 per utterance = D rounded up to the sweep's band + one band
   // fused additive joint only:
   float* mf2;      // [B][maxT]  max_v f(b,t,v) * log2(e)
   float* mg2;      // [B][maxU1] max_v g(b,u,v) * log2(e)
@@ -82,6 +87,20 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // sweep can load and store its columns unconditionally.
 inline int sweep_cols_per_lane(int maxU1) {
   return maxU1 <= 64 ? 1 : maxU1 <= 128 ? 2 : maxU1 <= 256 ? 4 : maxU1 <= 512 ? 8 : 16;
+}
+
+// Above 128 label positions the sweeps run one wavefront per 64 lattice columns (k_sweep_wide) over the records
+// re-ordered by anti-diagonal (k_skew_records); up to 128 one wavefront per utterance and direction (k_sweep).
+#ifndef RNNT_SWEEP_BAND
+#define RNNT_SWEEP_BAND 32
+#endif
+constexpr int kSweepBand = RNNT_SWEEP_BAND;  // diagonals between two block barriers of the wide sweep
+inline bool sweep_is_wide(int maxU1) {
+#ifdef RNNT_NO_WIDE_SWEEP
+  return false;
+#else
+  return maxU1 > 128;
+#endif
 }
 
 // The d g contraction has only B * (U1p/32) * (column strips) wavefront tiles, each summing over all frames: for a
@@ -124,6 +143,8 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
   const size_t o_rec = take(sizeof(float4) * (size_t)B * (maxT + 2) * maxU1);
   const size_t o_alpha = take(sizeof(double) * plane);
   const size_t o_beta = take(sizeof(double) * plane);
+  const int Dp = sweep_is_wide(maxU1) ? (D + kSweepBand - 1) / kSweepBand * kSweepBand + kSweepBand : 0;
+  const size_t o_lp2 = Dp ? take(sizeof(float2) * (size_t)B * Dp * U1s) : 0;
   const size_t o_mf2 = joint ? take(sizeof(float) * (size_t)B * maxT) : 0;
   const size_t o_mg2 = joint ? take(sizeof(float) * (size_t)B * maxU1) : 0;
   const size_t o_fblank = joint ? take(sizeof(float) * (size_t)B * maxT) : 0;
@@ -151,6 +172,8 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
     w->rec = reinterpret_cast<float4*>(p + o_rec);
     w->alpha = reinterpret_cast<double*>(p + o_alpha);
     w->beta = reinterpret_cast<double*>(p + o_beta);
+    w->lp2 = Dp ? reinterpret_cast<float2*>(p + o_lp2) : nullptr;
+    w->Dp = Dp;
     w->mf2 = joint ? reinterpret_cast<float*>(p + o_mf2) : nullptr;
     w->mg2 = joint ? reinterpret_cast<float*>(p + o_mg2) : nullptr;
     w->fblank = joint ? reinterpret_cast<float*>(p + o_fblank) : nullptr;

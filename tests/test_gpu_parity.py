@@ -225,6 +225,30 @@ def test_device_side_validation_flags():
     assert np.isfinite(run.x.cpu().numpy()).all()
 
 
+@pytest.mark.parametrize("U", [130, 200, 330])
+def test_wide_lattices_ragged_edges_and_a_malformed_length(U):
+    """More than 128 label positions: the sweeps run one wavefront per 64 columns, a band of diagonals apart.
+    Utterances whose last diagonal ends inside a band, one with no labels, one with a single frame, and one with an
+    impossible length (its block leaves before the first barrier) in the same batch."""
+    B, T, V, blank = 6, 70, 6, 2
+    x, lab, _, _ = make_batch(B, T, U, V, blank, seed=U, ragged=False)
+    il = np.array([T, 33, 64, 1, T, 17], np.int32)
+    ll = np.array([U, 127, 0, U, U - 1, 64], np.int32)
+    _check(x, lab, il, ll, blank)
+    bad = il.copy()
+    bad[1] = T + 1
+    run = HipRun(x, lab, bad, ll, blank)
+    assert run.loss_grad() == 0
+    rc, flags = run.flags()
+    assert rc == 4 and flags & 1
+    c = run.costs.cpu().numpy()
+    keep = [0, 2, 3, 4, 5]
+    assert np.isnan(c[1]) and not run.x.cpu().numpy()[1].any()
+    co, go = orc.rnnt_loss_and_grad(x[keep], lab[keep], il[keep], ll[keep], blank)
+    np.testing.assert_allclose(c[keep], co, rtol=COST_RTOL)
+    assert np.abs(run.x.cpu().numpy()[keep] - go).max() < GRAD_ATOL_TIGHT
+
+
 def test_deterministic_and_batch_independent():
     """Same inputs twice -> bit-identical outputs; an utterance's result does
     not depend on what else is in the batch."""
