@@ -94,12 +94,15 @@ inline int sweep_cols_per_lane(int maxU1) {
 #ifndef RNNT_SWEEP_BAND
 #define RNNT_SWEEP_BAND 32
 #endif
+#ifndef RNNT_SWEEP_WIDE_ABOVE  // (64 measured: 83 us against 63 us at T=500, U+1=101 -- the re-ordering pass and the band of skew cost more than one column per lane gains)
+#define RNNT_SWEEP_WIDE_ABOVE 128
+#endif
 constexpr int kSweepBand = RNNT_SWEEP_BAND;  // diagonals between two block barriers of the wide sweep
 inline bool sweep_is_wide(int maxU1) {
 #ifdef RNNT_NO_WIDE_SWEEP
   return false;
 #else
-  return maxU1 > 128;
+  return maxU1 > RNNT_SWEEP_WIDE_ABOVE;
 #endif
 }
 
