@@ -27,5 +27,7 @@ for name, fn, lo in (("abi", t.test_random_logits_through_the_c_abi, first), ("c
         except AssertionError as e:
             bad += 1
             print(name, seed, str(e)[:300].replace("\n", " "), flush=True)
+        if (seed - lo) % 25 == 24:
+            print(name, seed - lo + 1, "cases", flush=True)  # a long run shows that it is alive
     print(name, "done", flush=True)
 print("failures", bad)
