@@ -231,6 +231,30 @@ SmallGeom small_geom(const Call& c, int* blocks) {
     }                                                                                                           \
   } while (0)
 
+// the same instantiations for the one-shot form of the gradient pass (one wavefront per block)
+#define RNNT_SMALL_SPAN_LAUNCH(KERNEL, VEC, PAD, NLD, blocks, lds, st, ...)                                     \
+  do {                                                                                                          \
+    if ((lds) > 48 * 1024) /* per device, so not cached in a process-wide flag */                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<VEC, PAD, NLD>),                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                         \
+    KERNEL<VEC, PAD, NLD><<<blocks, 64, lds, st>>>(__VA_ARGS__);                                                \
+  } while (0)
+#define RNNT_SMALL_SPAN_DISPATCH(KERNEL, V, blocks, lds, st, ...)                                               \
+  do {                                                                                                          \
+    const int pm = small_pad_mode(V, true);                                                                     \
+    if ((V) <= 64) {                                                                                            \
+      if (pm == 1) RNNT_SMALL_SPAN_LAUNCH(KERNEL, 4, 1, 16, blocks, lds, st, __VA_ARGS__);                      \
+      else if ((V) % 4 == 0) RNNT_SMALL_SPAN_LAUNCH(KERNEL, 4, 0, 16, blocks, lds, st, __VA_ARGS__);            \
+      else if ((V) % 2 == 0) RNNT_SMALL_SPAN_LAUNCH(KERNEL, 2, 0, 16, blocks, lds, st, __VA_ARGS__);            \
+      else RNNT_SMALL_SPAN_LAUNCH(KERNEL, 1, 0, 16, blocks, lds, st, __VA_ARGS__);                              \
+    } else {                                                                                                    \
+      if (pm == 2) RNNT_SMALL_SPAN_LAUNCH(KERNEL, 4, 2, 32, blocks, lds, st, __VA_ARGS__);                      \
+      else if ((V) % 4 == 0) RNNT_SMALL_SPAN_LAUNCH(KERNEL, 4, 0, 32, blocks, lds, st, __VA_ARGS__);            \
+      else if ((V) % 2 == 0) RNNT_SMALL_SPAN_LAUNCH(KERNEL, 2, 0, 32, blocks, lds, st, __VA_ARGS__);            \
+      else RNNT_SMALL_SPAN_LAUNCH(KERNEL, 1, 0, 32, blocks, lds, st, __VA_ARGS__);                              \
+    }                                                                                                           \
+  } while (0)
+
 SpanGeom span_geom(const Call& c, int b0) {
   SpanGeom sg;
   sg.maxT = c.maxT; sg.maxU1 = c.maxU1; sg.V = c.V; sg.blank = c.blank;
@@ -347,6 +371,17 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
     const size_t skip = (size_t)c.t_off * c.maxU1 * c.V;  // the cropped frames are rows without a cell: zero-filled
     const float* x0 = c.logits - skip;
     float* g0 = c.grad - skip;
+#ifndef RNNT_NO_SMALL_SPAN
+    {  // one block per tile (plus one for a partial last tile), when the per-block slots of the workspace suffice
+      const long long sblocks = (long long)g.ntiles_full + ((long long)g.ntiles_full * 64 < g.total_rows ? 1 : 0);
+      const size_t slds = sizeof(float4) * (size_t)small_lds_f4(c.V, true);
+      if (sblocks >= 1 && (size_t)sblocks <= ws_partial_slots(c.B, c.maxT, c.maxU1)) {
+        RNNT_SMALL_SPAN_DISPATCH(k_grad_small_span, c.V, (int)sblocks, slds, st, x0, g0, c.labels, c.in_len, c.lab_len,
+                                 c.grad_scale, g, c.w);
+        return;
+      }
+    }
+#endif
     RNNT_SMALL_DISPATCH(k_grad_small, c.V, true, blocks, lds, st, x0, g0, c.labels, c.in_len, c.lab_len, c.grad_scale, g, c.w);
     return;
   }

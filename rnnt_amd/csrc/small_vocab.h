@@ -470,4 +470,158 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_grad_small_span: the arithmetic and the tile layout of k_grad_small, one tile per wavefront and no loop.
+//
+// k_grad_small's persistent waves go from tile to tile, and because its loads and stores are conditional the
+// compiler cannot count them: every wait in its loop is s_waitcnt vmcnt(0), i.e. a wave drains the previous tile's
+// stores before it touches the next tile (about 14 us per tile and wave under load, with 10 waves per compute unit
+// -- as many as their 16 KiB LDS tiles allow).  A wavefront that ends may leave its stores in flight.  So here a
+// block is one wavefront that handles exactly one tile and exits; the lengths and the whole cell state are requested
+// in one round trip (clamped addresses), the gated rows in a second.  Measured at B=32, T=500, U=100, V=62: 141 ->
+// 130 us on N(0,1) logits, 132 -> 119 us on peaked ones, 176 -> 151 us without pruning.  (Blocks of 2 or 4 such
+// wavefronts with a barrier between their loads and their stores: the same or slower.  Wavefronts of a block taking
+// turns on one LDS tile, so that residency is set by registers instead of LDS, 16-20 waves per compute unit: slower.)
+// ---------------------------------------------------------------------------
+template <int VEC, int PAD, int NLD>
+__global__ __launch_bounds__(64) void k_grad_small_span(const float* x, float* grad, const int32_t* __restrict__ labels,
+                                                        const int32_t* __restrict__ in_len,
+                                                        const int32_t* __restrict__ lab_len,
+                                                        const float* __restrict__ grad_scale, SmallGeom g, Ws w) {
+  extern __shared__ float4 lds4[];
+  const int lane = threadIdx.x;
+  const int V = g.V;
+  const int tile_f4 = 16 * V;
+  float4* tile4 = lds4;
+  float* rowp = reinterpret_cast<float*>(tile4) + lane * (V + (PAD ? 4 : 0));
+  const unsigned recip = PAD == 2 ? (65536u + (unsigned)(V / 4) - 1u) / (unsigned)(V / 4) : 0u;
+  auto slot = [&](int q) {  // see k_lse_small
+    return PAD == 1 ? q + (q >> 4) : PAD == 2 ? q + (int)(__umul24((unsigned)q, recip) >> 16) : q;
+  };
+  const f4v* x4 = reinterpret_cast<const f4v*>(x);
+  f4v* g4 = reinterpret_cast<f4v*>(grad);
+  if (blockIdx.x == 0 && lane == 0) w.hdr->n_partial = gridDim.x;
+
+  // rows [row_lo(i), row_hi(i)] of a tile overlap its i-th KiB: that load is needed iff one of them is active
+  auto chunk_needed = [&](unsigned long long active, int i) {
+    const int row_bytes = 4 * V;
+    const int lo = (1024 * i) / row_bytes;
+    const int hi = min(63, (1024 * i + 1023) / row_bytes);
+    const unsigned long long m = (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+    return (active & m) != 0ull;
+  };
+
+  // tiles in the reverse of k_lse_small's order (most recently read rows first).  The grid has one block per whole
+  // tile, and one more when the tensor ends in a partial tile (block 0 then takes those rows, one per lane, straight
+  // in global memory).
+  const bool has_tail = (long long)g.ntiles_full * 64 < g.total_rows;
+  const int k = (int)blockIdx.x - (has_tail ? 1 : 0);
+  float sqsum = 0.f;
+  int n_cell = 0, n_pruned = 0;
+  if (k < 0) {
+    const long long row = (long long)g.ntiles_full * 64 + lane;
+    int b = -1, t, u, T = 0, U = 0;
+    bool in_range;
+    small_decode(row, g, in_len, lab_len, b, t, u, T, U, in_range);
+    bool cell = false, pruned = false;
+    if (row < g.total_rows) {
+      const CellRaw rl = cell_load(w, labels, b, t, u, T, U, g.maxT, g.maxU1, V, in_range);
+      const float4 c = cell_coef(rl, g.prune_log2);
+      cell = rl.flags & 1;
+      pruned = cell && !(c.x > -INFINITY);
+      float* gp = grad + (size_t)row * V;
+      if (c.x > -INFINITY) {
+        sqsum += small_row_grad<1>(x + (size_t)row * V, gp, V, g.blank, c, grad_scale ? grad_scale[b] : 1.f);
+      } else {
+        for (int i = 0; i < V; ++i) gp[i] = 0.f;
+      }
+    }
+    n_cell = __popcll(__ballot(cell));
+    n_pruned = __popcll(__ballot(pruned));
+  } else {
+    const int n = g.ntiles_full - 1 - k;
+    // The lengths and everything a cell needs are requested at once (addresses clamped into the arrays; what is
+    // loaded for a row without a cell is not used): one round trip to memory ahead of the row loads, not two.
+    const unsigned rr = (unsigned)n * 64u + (unsigned)lane;  // < total_rows < 2^31
+    const unsigned per_b = (unsigned)g.frames * (unsigned)g.maxU1;
+    const int b = (int)(rr / per_b);
+    const unsigned rem = rr - (unsigned)b * per_b;
+    const int tf = (int)(rem / (unsigned)g.maxU1);
+    const int u = (int)(rem - (unsigned)tf * (unsigned)g.maxU1);
+    const bool in_range = tf >= g.t_off;
+    const int t = max(tf - g.t_off, 0);
+    const int U1s = w.U1s;
+    const size_t ci = ((size_t)b * w.D + (t + u)) * U1s + u;
+    const size_t ci_t = (t + u + 1 < w.D) ? ci + U1s : ci;
+    const size_t ci_u = (u + 1 < U1s) ? ci_t + 1 : ci_t;
+    const int Traw = in_len[b], Uraw = lab_len[b];
+    CellRaw r0;
+    r0.a = w.alpha[ci];
+    r0.be = w.beta[ci];
+    r0.be_t = w.beta[ci_t];
+    r0.be_u = w.beta[ci_u];
+    r0.ll = w.ll[b];
+    r0.rc = w.rec[((size_t)b * (g.maxT + 2) + 1 + t) * g.maxU1 + u];
+    int lab = 0;
+    if (g.maxU1 > 1) lab = labels[(size_t)b * (g.maxU1 - 1) + min(u, g.maxU1 - 2)];
+    const float sc = grad_scale ? grad_scale[b] : 1.f;
+    const bool ok = (Traw >= 1) & (Traw <= g.maxT) & (Uraw >= 0) & (Uraw <= g.maxU1 - 1);
+    const int T = ok ? Traw : 0, U = ok ? Uraw : 0;
+    const bool is_cell = in_range && t < T && u <= U;
+    r0.flags = is_cell ? (1 | (t < T - 1 ? 2 : 0) | (u == U ? 4 : 0) | (u < U ? 8 : 0)) : 0;
+    r0.lab = (u < U) ? ((lab < 0 || lab >= V) ? 0 : lab) : -1;
+    const float4 cf = cell_coef(r0, g.prune_log2);
+    n_cell = __popcll(__ballot(r0.flags & 1));
+    n_pruned = __popcll(__ballot((r0.flags & 1) && !(cf.x > -INFINITY)));
+    const unsigned long long active = __ballot(cf.x > -INFINITY);
+    f4v* dst = g4 + (size_t)n * tile_f4;
+    if (active == 0ull) {  // no active row: zeros straight to memory
+      const f4v z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int q = lane + 64 * i;
+        if (q < tile_f4) __builtin_nontemporal_store(z, dst + q);
+      }
+    } else {
+      const f4v* src = x4 + (size_t)n * tile_f4;
+      f4v st[NLD];
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int q = lane + 64 * i;
+        if (chunk_needed(active, i) && q < tile_f4) st[i] = __builtin_nontemporal_load(src + q);
+      }
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int q = lane + 64 * i;
+        if (chunk_needed(active, i) && q < tile_f4) tile4[slot(q)] = make_float4(st[i].x, st[i].y, st[i].z, st[i].w);
+      }
+      // (one wavefront: its LDS accesses are in program order, no barrier)
+      if (cf.x > -INFINITY) {
+        sqsum += small_row_grad<VEC>(rowp, rowp, V, g.blank, cf, sc);
+      } else {
+        for (int i = 0; i < V; i += VEC) {
+          if constexpr (VEC == 4) *reinterpret_cast<float4*>(rowp + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+          else if constexpr (VEC == 2) *reinterpret_cast<float2*>(rowp + i) = make_float2(0.f, 0.f);
+          else rowp[i] = 0.f;
+        }
+      }
+      // the whole tile (gradients and zero rows) leaves as coalesced 1 KiB stores
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int q = lane + 64 * i;
+        if (q < tile_f4) {
+          const float4 o = tile4[slot(q)];
+          f4v ov = {o.x, o.y, o.z, o.w};
+          __builtin_nontemporal_store(ov, dst + q);
+        }
+      }
+    }
+  }
+  sqsum = group_sum<64>(sqsum);
+  if (lane == 0) {
+    w.partial[blockIdx.x] = sqsum;
+    w.pcount[blockIdx.x] = make_uint2((unsigned)n_cell, (unsigned)n_pruned);
+  }
+}
+
 }  // namespace

@@ -16,7 +16,7 @@ ap.add_argument("--extra", default="")
 ap.add_argument("--kinds", default="n1,peaked")
 ap.add_argument("names", nargs="+")
 a = ap.parse_args()
-kinds = {"n1": [], "peaked": ["--logit-scale", "10"], "off": ["--prune-log2", "-inf"], "p28": ["--prune-log2", "-28"]}
+kinds = {"n1": [], "peaked": ["--logit-scale", "10"], "off": ["--prune-log2=-inf"], "p28": ["--prune-log2=-28"]}
 for name in a.names:
     lib = os.path.join(ROOT, "tools", "variants", name + ".so")
     for kind in a.kinds.split(","):
