@@ -239,9 +239,9 @@ SmallGeom small_geom(const Call& c, int* blocks) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                         \
     KERNEL<VEC, PAD, NLD><<<blocks, 64, lds, st>>>(__VA_ARGS__);                                                \
   } while (0)
-#define RNNT_SMALL_SPAN_DISPATCH(KERNEL, V, blocks, lds, st, ...)                                               \
+#define RNNT_SMALL_SPAN_DISPATCH(KERNEL, V, GRAD, blocks, lds, st, ...)                                         \
   do {                                                                                                          \
-    const int pm = small_pad_mode(V, true);                                                                     \
+    const int pm = small_pad_mode(V, GRAD);                                                                     \
     if ((V) <= 64) {                                                                                            \
       if (pm == 1) RNNT_SMALL_SPAN_LAUNCH(KERNEL, 4, 1, 16, blocks, lds, st, __VA_ARGS__);                      \
       else if ((V) % 4 == 0) RNNT_SMALL_SPAN_LAUNCH(KERNEL, 4, 0, 16, blocks, lds, st, __VA_ARGS__);            \
@@ -272,6 +272,17 @@ void launch_lse(const Call& c, int b0, int nb, hipStream_t st) {
     const SmallGeom g = small_geom(c, &blocks);
     const size_t lds = sizeof(float4) * (size_t)small_lds_f4(c.V, false) * kSmallWaves;
     const float* x0 = c.logits - (size_t)c.t_off * c.maxU1 * c.V;  // frame 0 of the uncropped tensor
+#ifndef RNNT_NO_SMALL_LSE_SPAN
+    // One-shot blocks up to 112 logits (B=64, T=500, U=100: V=32 95 -> 83 us, 62 159 -> 151, 80 291 -> 206, 100 309 -> 257;
+    // 108..124 alike); the largest tiles keep the persistent, pipelined kernel (V=126 353 against 390 us, 128 315
+    // against 357: with 32 KiB of LDS per tile too few one-shot wavefronts are resident to overlap on their own).
+    if (c.V <= 112) {  // one block per tile (plus one for a partial last tile)
+      const long long sblocks = (long long)g.ntiles_full + ((long long)g.ntiles_full * 64 < g.total_rows ? 1 : 0);
+      const size_t slds = sizeof(float4) * (size_t)small_lds_f4(c.V, false);
+      RNNT_SMALL_SPAN_DISPATCH(k_lse_small_span, c.V, false, (int)sblocks, slds, st, x0, c.labels, c.in_len, c.lab_len, g, c.w);
+      return;
+    }
+#endif
     RNNT_SMALL_DISPATCH(k_lse_small, c.V, false, blocks, lds, st, x0, c.labels, c.in_len, c.lab_len, g, c.w);
     return;
   }
@@ -376,7 +387,7 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
       const long long sblocks = (long long)g.ntiles_full + ((long long)g.ntiles_full * 64 < g.total_rows ? 1 : 0);
       const size_t slds = sizeof(float4) * (size_t)small_lds_f4(c.V, true);
       if (sblocks >= 1 && (size_t)sblocks <= ws_partial_slots(c.B, c.maxT, c.maxU1)) {
-        RNNT_SMALL_SPAN_DISPATCH(k_grad_small_span, c.V, (int)sblocks, slds, st, x0, g0, c.labels, c.in_len, c.lab_len,
+        RNNT_SMALL_SPAN_DISPATCH(k_grad_small_span, c.V, true, (int)sblocks, slds, st, x0, g0, c.labels, c.in_len, c.lab_len,
                                  c.grad_scale, g, c.w);
         return;
       }

@@ -243,6 +243,98 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_lse_small_span: k_lse_small with one tile per wavefront and no loop (see k_grad_small_span below: a block is one
+// wavefront that handles one tile and exits, so nothing it stores is ever waited for, and the hardware's block
+// scheduler does the pipelining).  Lengths and label first (a short round trip: a few addresses per tile, mostly
+// cache hits), then the tile's rows if one of them holds a cell.
+// ---------------------------------------------------------------------------
+template <int VEC, int PAD, int NLD>
+__global__ __launch_bounds__(64) void k_lse_small_span(const float* __restrict__ x, const int32_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ in_len,
+                                                       const int32_t* __restrict__ lab_len, SmallGeom g, Ws w) {
+  extern __shared__ float4 lds4[];
+  const int lane = threadIdx.x;
+  const int V = g.V;
+  const int tile_f4 = 16 * V;
+  float4* tile4 = lds4;
+  const float* rowp = reinterpret_cast<const float*>(tile4) + lane * (V + (PAD ? 4 : 0));
+  const unsigned recip = PAD == 2 ? (65536u + (unsigned)(V / 4) - 1u) / (unsigned)(V / 4) : 0u;
+  auto slot = [&](int q) {  // see k_lse_small
+    return PAD == 1 ? q + (q >> 4) : PAD == 2 ? q + (int)(__umul24((unsigned)q, recip) >> 16) : q;
+  };
+  const f4v* x4 = reinterpret_cast<const f4v*>(x);
+  const bool has_tail = (long long)g.ntiles_full * 64 < g.total_rows;
+  const int n = (int)blockIdx.x - (has_tail ? 1 : 0);
+  if (n < 0) {  // the last, partial tile (fewer than 64 rows): rows straight from global memory
+    const long long row = (long long)g.ntiles_full * 64 + lane;
+    int b = -1, t, u, T = 0, U = 0;
+    bool in_range;
+    small_decode(row, g, in_len, lab_len, b, t, u, T, U, in_range);
+    if (in_range) {
+      float4 rc = make_float4(kNegF, kNegF, 0.f, 0.f);
+      if (t < T && u <= U) {
+        const float* rp = x + (size_t)row * V;
+        float m2, ls;
+        small_row_lse2<1>(rp, V, m2, ls);
+        float lpl = kNegF;
+        if (u < U) {
+          int lab = labels[(size_t)b * (g.maxU1 - 1) + u];
+          if (lab < 0 || lab >= V) {
+            atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
+            lab = 0;
+          }
+          lpl = __builtin_fmaf(rp[lab], kLog2e, -m2) - ls;
+        }
+        rc = make_float4(__builtin_fmaf(rp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, 0.f);
+      }
+      small_write_record(w, g, b, t, u, rc);
+    }
+    return;
+  }
+  const unsigned rr = (unsigned)n * 64u + (unsigned)lane;  // < total_rows < 2^31
+  const unsigned per_b = (unsigned)g.frames * (unsigned)g.maxU1;
+  const int b = (int)(rr / per_b);
+  const unsigned rem = rr - (unsigned)b * per_b;
+  const int tf = (int)(rem / (unsigned)g.maxU1);
+  const int u = (int)(rem - (unsigned)tf * (unsigned)g.maxU1);
+  const bool in_range = tf >= g.t_off;
+  const int t = max(tf - g.t_off, 0);
+  const int Traw = in_len[b], Uraw = lab_len[b];
+  int lab = 0;
+  if (g.maxU1 > 1) lab = labels[(size_t)b * (g.maxU1 - 1) + min(u, g.maxU1 - 2)];
+  const bool ok = (Traw >= 1) & (Traw <= g.maxT) & (Uraw >= 0) & (Uraw <= g.maxU1 - 1);
+  const int T = ok ? Traw : 0, U = ok ? Uraw : 0;
+  const bool valid = in_range & (t < T) & (u <= U);
+  float4 rc = make_float4(kNegF, kNegF, 0.f, 0.f);
+  if (__ballot(valid) != 0ull) {  // wave-uniform
+    const f4v* src = x4 + (size_t)n * tile_f4;
+    f4v st[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) st[i] = __builtin_nontemporal_load(src + min(lane + 64 * i, tile_f4 - 1));
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int q = min(lane + 64 * i, tile_f4 - 1);
+      tile4[slot(q)] = make_float4(st[i].x, st[i].y, st[i].z, st[i].w);
+    }
+    // (one wavefront: its LDS accesses are in program order, no barrier)
+    if (valid) {
+      float m2, ls;
+      small_row_lse2<VEC>(rowp, V, m2, ls);
+      float lpl = kNegF;
+      if (u < U) {
+        if (lab < 0 || lab >= V) {
+          atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
+          lab = 0;
+        }
+        lpl = __builtin_fmaf(rowp[lab], kLog2e, -m2) - ls;
+      }
+      rc = make_float4(__builtin_fmaf(rowp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, 0.f);
+    }
+  }
+  if (in_range) small_write_record(w, g, b, t, u, rc);
+}
+
 // Everything the gradient of a row needs about its lattice cell, as loaded (no arithmetic yet, so that the
 // loads can be issued a tile ahead of their use).
 struct CellRaw {
