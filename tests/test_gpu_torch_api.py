@@ -382,9 +382,11 @@ def test_entry_points_can_be_captured_in_a_hip_graph():
 
 
 # B, T0, t_offset, U, V, blank: small-vocabulary tiles (64 rows) with cropped frames inside full tiles, inside the
-# last partial tile only, and a large vocabulary (generic kernels + zero-fill of the cropped frames)
+# last partial tile only, a large vocabulary (generic kernels + zero-fill of the cropped frames), and crops that
+# skip nearly the whole tensor (more tiles than the workspace has per-block slots for the lattice that is left:
+# the gradient pass then takes its persistent form)
 CROP_SHAPES = [(2, 3, 2, 0, 5, 0), (3, 9, 2, 4, 62, 39), (2, 40, 3, 7, 40, 39), (1, 5, 4, 2, 16, 1), (2, 7, 2, 3, 300, 7),
-               (2, 6, 1, 3, 1024, 0)]
+               (2, 6, 1, 3, 1024, 0), (1, 70, 68, 20, 62, 39), (2, 90, 87, 9, 50, 3)]
 
 
 @pytest.mark.parametrize("B,T0,off,U,V,blank", CROP_SHAPES)
