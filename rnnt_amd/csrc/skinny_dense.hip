@@ -11,6 +11,7 @@
 //                 straight from global memory (whole rows per wavefront load); db = column sums on the vector unit
 //   k_dense_wgrad_reduce   sums the partials in block order (no atomics: bit-reproducible)
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -62,12 +63,13 @@ __device__ __forceinline__ void loadn(const float* p, int col, int ncol, bool ro
 // g the upstream gradient and z the layer's forward output.  W arrives as wt[k][n] = W[k][n] (TRANS = false) or
 // W[n][k] (TRANS = true: the data gradient multiplies by W^T).  Kd = contraction length, Nd = output columns.
 // LDS: W zero-padded to [Kp][Np + 4].  Lane l of MFMA tile j owns output column NT*(l%32) + j.
-// Resident waves per SIMD asked of the compiler: 6 with up to 64 output columns (5 where the activation gradient is
-// folded in: 6 spills), 4 with 128 columns (two 32 x 64 accumulators more).  Blocks of 8 waves share one copy of
+// Resident waves per SIMD asked of the compiler: 5 with up to 64 output columns (6 spills 11 registers, and spill
+// traffic shares the memory counter: K=100, N=62 276 us with 5 against 312 us with 6 once the loop's waits are
+// counted), 4 with 128 columns (two 32 x 64 accumulators more).  Blocks of 8 waves share one copy of
 // W in LDS: with 4-wave blocks the 55-68 KB of a 128-column W left room for two blocks = 2 waves per SIMD
 // (K=100, N=100 forward 495 -> 450 us; K=64, N=40 216 -> 185 us; K=100, N=62 unchanged within noise).
-#ifndef RNNT_DENSE_FWD_WPE
-#define RNNT_DENSE_FWD_WPE 6
+#ifndef RNNT_DENSE_FWD_WPE  // 5: the counted path below needs a build without spills (spill traffic shares the counter)
+#define RNNT_DENSE_FWD_WPE 5
 #endif
 #ifndef RNNT_DENSE_FWD_BLOCK
 #define RNNT_DENSE_FWD_BLOCK 512
@@ -89,7 +91,17 @@ __global__ __launch_bounds__(kFwdBlock) __attribute__((amdgpu_waves_per_eu(NT <=
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5;
-  const int col = NT * l32;
+  // Counted waits (the COUNTED path below).  A wave's memory operations complete in order and are waited for by
+  // count.  The next tile's first loads are issued before this tile's 16 stores, so waiting for them need not wait
+  // for the stores -- if the compiler can count the stores.  It cannot count conditional ones, and then "my loads
+  // have arrived" turns into "nothing is outstanding": every tile waited for its predecessor's stores to land
+  // (stores knocked out: 310 -> 240 us at K=100, N=62), and every wait for a load also drained the loads issued
+  // after it.  So, where the shapes allow it, nothing in the loop is conditional: lanes whose NT columns lie beyond
+  // Nd work on the last NT columns that exist (the same products, the same stores to the same addresses as the lane
+  // that owns them), chunks beyond Kd re-read the row's last chunk (and are multiplied by the zero rows of W),
+  // rounds beyond Kp and tiles beyond the last are loaded from clamped addresses and not used.
+  const bool dup_ok = NT > 1 && yvec_ok && Nd % NT == 0 && Nd >= NT;  // uniform
+  const int col = dup_ok ? min(NT * l32, Nd - NT) : NT * l32;
   float bv[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) bv[j] = (bias && col + j < Nd) ? bias[col + j] : 0.f;
@@ -133,6 +145,86 @@ __global__ __launch_bounds__(kFwdBlock) __attribute__((amdgpu_waves_per_eu(NT <=
       }
     }
   };
+#ifndef RNNT_DENSE_NO_COUNTED
+  if (PIPE && AVEC == 4 && dup_ok && Kd % 4 == 0 && Kd >= 4 && wave0 < tiles) {  // uniform
+    auto issue_u = [&](long long tile, int k0) {
+      const long long mrow = min(tile * 32 + l32, M - 1);
+      const float* ap = a + (size_t)mrow * Kd;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f4v t = *reinterpret_cast<const f4v*>(ap + min(k0 + 8 * q + 4 * h, Kd - 4));
+        nxt[q][0] = t[0]; nxt[q][1] = t[1]; nxt[q][2] = t[2]; nxt[q][3] = t[3];
+      }
+    };
+    issue_u(wave0, 0);
+    // one tile: products, then its stores -- unconditional for a whole tile (WHOLE), row by row for the last, partial
+    // one, which is peeled out of the loop: a conditional store anywhere in the loop makes its stores uncountable
+    auto do_tile = [&](long long tile, auto whole) {
+      const long long m0 = tile * 32;
+      const long long ntile = tile + nwaves < tiles ? tile + nwaves : tile;
+      f16v acc[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      for (int k0 = 0; k0 < Kp; k0 += 32) {
+        float av[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) av[q][i] = (k0 + 8 * q + 4 * h < Kd) ? nxt[q][i] : 0.f;
+        const bool more = k0 + 32 < Kp;
+        issue_u(more ? tile : ntile, more ? k0 + 32 : 0);  // the next round, of this tile or of the wave's next one
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kq = k0 + 8 * q;
+          if (kq < Kp) {  // uniform; no memory operation inside
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float* wr = wl + (kq + 4 * h + i) * pitch + col;
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][i], wr[j], acc[j], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long m = m0 + mm_row(r, lane);
+        if (!decltype(whole)::value && m >= M) continue;
+        float o[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float v = acc[j][r] + bv[j];
+          if (act == 1) {
+            const float e = __builtin_amdgcn_exp2f(v * 2.885390081777927f);
+            v = __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+          }
+          o[j] = v;
+        }
+        float* yp = y + (size_t)m * Nd + col;
+        if constexpr (NT == 4) {
+          const f4v t = {o[0], o[1], o[2], o[3]};
+          *reinterpret_cast<f4v*>(yp) = t;
+        } else if constexpr (NT == 2) {
+          const f2v t = {o[0], o[1]};
+          *reinterpret_cast<f2v*>(yp) = t;
+        }
+      }
+    };
+    const long long full = M / 32;  // whole tiles
+    long long tile = wave0;
+    // (the wave's first tile is peeled as well: entered from it, the loop finds 16 stores behind the loads it waits
+    // for on every path; entered from the prologue it would find none on one, and count none)
+    if (tile < full) {
+      do_tile(tile, std::true_type{});
+      tile += nwaves;
+    }
+    for (; tile < full; tile += nwaves) do_tile(tile, std::true_type{});
+    if (tile < tiles) do_tile(tile, std::false_type{});
+    return;
+  }
+#endif
   if (PIPE && wave0 < tiles) issue(wave0, 0);
   for (long long tile = wave0; tile < tiles; tile += nwaves) {
     const long long m0 = tile * 32;
