@@ -146,14 +146,22 @@ __global__ __launch_bounds__(kFwdBlock) __attribute__((amdgpu_waves_per_eu(NT <=
     }
   };
 #ifndef RNNT_DENSE_NO_COUNTED
-  if (PIPE && AVEC == 4 && dup_ok && Kd % 4 == 0 && Kd >= 4 && wave0 < tiles) {  // uniform
+  constexpr bool COUNTED = !DACT && (AVEC == 4 || AVEC == 2);
+  if (COUNTED && dup_ok && Kd % AVEC == 0 && Kd >= 4 && wave0 < tiles) {  // uniform
     auto issue_u = [&](long long tile, int k0) {
       const long long mrow = min(tile * 32 + l32, M - 1);
       const float* ap = a + (size_t)mrow * Kd;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f4v t = *reinterpret_cast<const f4v*>(ap + min(k0 + 8 * q + 4 * h, Kd - 4));
-        nxt[q][0] = t[0]; nxt[q][1] = t[1]; nxt[q][2] = t[2]; nxt[q][3] = t[3];
+        const int c = k0 + 8 * q + 4 * h;
+        if constexpr (AVEC == 4) {
+          const f4v t = *reinterpret_cast<const f4v*>(ap + min(c, Kd - 4));
+          nxt[q][0] = t[0]; nxt[q][1] = t[1]; nxt[q][2] = t[2]; nxt[q][3] = t[3];
+        } else {  // rows of whole 8-byte pieces: a chunk of four may end inside the row
+          const f2v t0 = *reinterpret_cast<const f2v*>(ap + min(c, Kd - 2));
+          const f2v t1 = *reinterpret_cast<const f2v*>(ap + min(c + 2, Kd - 2));
+          nxt[q][0] = t0[0]; nxt[q][1] = t0[1]; nxt[q][2] = t1[0]; nxt[q][3] = t1[1];
+        }
       }
     };
     issue_u(wave0, 0);
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(kFwdBlock) __attribute__((amdgpu_waves_per_eu(NT <=
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) av[q][i] = (k0 + 8 * q + 4 * h < Kd) ? nxt[q][i] : 0.f;
+          for (int i = 0; i < 4; ++i) av[q][i] = (k0 + 8 * q + 4 * h + i < Kd) ? nxt[q][i] : 0.f;
         const bool more = k0 + 32 < Kp;
         issue_u(more ? tile : ntile, more ? k0 + 32 : 0);  // the next round, of this tile or of the wave's next one
 #pragma unroll
