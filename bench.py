@@ -293,7 +293,13 @@ def run_rank(args) -> None:
     nbytes = master.numel() * 4
     free, _total = torch.cuda.mem_get_info(dev)
     total_steps = args.steps + args.warmup
-    ring_n = args.ring if args.ring > 0 else max(1, min(total_steps, int((free - (8 << 30)) // nbytes), 24))
+    # ranks that share a device (gloo rehearsals on a one-GPU box) share its memory: each plans with its share
+    share = free // max(1, -(-world // n_dev))
+    ring_n = args.ring if args.ring > 0 else max(1, min(total_steps, int((share - (8 << 30)) // nbytes), 24))
+    if multi:  # every rank must cut its steps into the same segments: the fences between them are collectives
+        rn = torch.tensor([ring_n], dtype=torch.int64, device=comm_dev)
+        dist.all_reduce(rn, op=dist.ReduceOp.MIN)
+        ring_n = int(rn.item())
     ring = [torch.empty_like(master) for _ in range(ring_n)]
     scal = torch.zeros((max(ring_n, 1), 2), dtype=torch.float64, device=dev)  # one slot per step of a segment
 
