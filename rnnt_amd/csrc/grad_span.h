@@ -32,6 +32,9 @@ namespace {
 #ifndef RNNT_SPAN_NG  // row groups per wave for rows of up to 4 KiB (a multiple of 4)
 #define RNNT_SPAN_NG 8
 #endif
+#ifndef RNNT_SPAN_PACE  // stores (of 1 KiB per wavefront) between two drains of the write phase; 0 = leave it to the compiler
+#define RNNT_SPAN_PACE 4
+#endif
 constexpr int kSpanWaves = RNNT_SPAN_WAVES;
 constexpr int kSpanMaxRows = 512;  // rows per block, upper bound over the instantiations
 
@@ -153,6 +156,20 @@ __global__ __launch_bounds__(kSpanWaves * 64) void k_grad_span(const float* x, f
     }
   }
   __syncthreads();  // the whole span turns from reading to writing
+#if RNNT_SPAN_PACE > 0
+  // The write phase is paced on purpose.  How many stores a wavefront has in flight matters on this memory system:
+  // measured at V = 1024 on N(0,1) / peaked logits, a drain after every 1 / 2 / 4 / 8 / 16 / 32 stores of 1 KiB gives
+  // 2.85 / 2.49 / 2.31 / 2.31 / 2.35 / 2.40 ms and 2.18 / 1.90 / 1.81 / 1.87 / 1.90 / 1.94 ms.  Every row register is
+  // made "used" here, so that the ONE wait for the (conditional, hence uncountable) row loads stands in straight-line
+  // code ahead of the first store; left to itself the compiler puts an s_waitcnt vmcnt(0) in front of every row
+  // group's arithmetic, which paces the stores by accident (4 per drain at V = 1024: 2.35 / 1.81 ms; 16 at V = 4096).
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(v[g][i][q]));
+#endif
 
   // ---- write phase
   float sqsum = 0.f;
@@ -186,6 +203,9 @@ __global__ __launch_bounds__(kSpanWaves * 64) void k_grad_span(const float* x, f
         }
         store_vec<4>(gp + (size_t)c * 4, o);
       }
+#if RNNT_SPAN_PACE > 0
+      if ((g * NC + i + 1) % RNNT_SPAN_PACE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     }
   }
 
