@@ -13,8 +13,9 @@ from tests.hip_runner import HipRun, make_batch, _p
 pytestmark = pytest.mark.gpu
 
 # (B, T, U, V, blank): a large-vocabulary shape first, then a smaller small-vocabulary one that reuses the same
-# built-in array while it still holds the first call's lattice
-CALLS = [(6, 70, 20, 1024, 1023, 11), (3, 33, 9, 62, 39, 12)]
+# built-in array while it still holds the first call's lattice, then a lattice of more than 128 label positions
+# (whose sweeps also keep their anti-diagonal copy of the log-probabilities in that array)
+CALLS = [(6, 70, 20, 1024, 1023, 11), (3, 33, 9, 62, 39, 12), (2, 40, 150, 8, 0, 13)]
 
 
 def _static_call(x, lab, il, ll, blank, gs):
