@@ -245,9 +245,9 @@ def run_rank(args) -> None:
 
     from rnnt_amd import _lib, sharding
     L = _lib.lib()
-    if args.prune_log2 is not None:
-        _lib.check(L.rnnt_mi355x_set_prune_log2(args.prune_log2), "rnnt_mi355x_set_prune_log2")
-    prune_log2 = float(L.rnnt_mi355x_get_prune_log2())
+    # the threshold is an argument of every call (the library's process default when none is given here)
+    prune_log2 = float(L.rnnt_mi355x_get_prune_log2()) if args.prune_log2 is None else float(args.prune_log2)
+    call_prune = [_lib.prune_arg(prune_log2)]  # what launch() passes; the extra legs change it
 
     cfg = dict(CONFIGS[args.config])
     if args.batch:
@@ -338,7 +338,7 @@ def run_rank(args) -> None:
         if events is not None:
             arr = (ctypes.c_void_p * 4)(*[None if e is None else ctypes.c_void_p(e.cuda_event) for e in events[:4]])
         rc = L.rnnt_mi355x_loss_grad_events(_p(ring[i]), _p(labels), _p(il), _p(ll), *meta, _p(grad_scale), _p(costs),
-                                            _p(ws), s, arr)
+                                            _p(ws), s, call_prune[0], arr)
         rc |= L.rnnt_mi355x_reduce_scalars(_p(costs), B, _p(ws), _p(scal[i]), s)
         if rc != 0:
             raise RuntimeError(f"rnnt_mi355x call failed: status {rc}")
@@ -554,9 +554,9 @@ def run_rank(args) -> None:
 
         if args.graph:
             args.graph = False
-        _lib.check(L.rnnt_mi355x_set_prune_log2(float("-inf")), "rnnt_mi355x_set_prune_log2")
+        call_prune[0] = float("-inf")
         leg("prune_off", "same inputs, pruning disabled: every row is read twice and written once")
-        _lib.check(L.rnnt_mi355x_set_prune_log2(prune_log2), "rnnt_mi355x_set_prune_log2")
+        call_prune[0] = _lib.prune_arg(prune_log2)
         master.mul_(10.0 / args.logit_scale)
         leg("peaked", "logits ~ N(0,1)*10 (posteriors as peaked as a trained model's), same pruning threshold")
         out["legs"] = legs

@@ -32,8 +32,16 @@
  *     (a hipStream_t, NULL = default stream; its device must be the current
  *     one) and, except rnnt_mi355x_read_status / rnnt_mi355x_read_stats, none
  *     synchronises; the only state the library keeps between calls is the
- *     pruning threshold of rnnt_mi355x_set_prune_log2 and, per device, the
- *     address of the built-in workspace of rnnt_mi355x_loss_grad_static;
+ *     default pruning threshold of rnnt_mi355x_set_prune_log2 (used only by
+ *     calls that pass NaN as their own) and, per device, the address of the
+ *     built-in workspace of rnnt_mi355x_loss_grad_static;
+ *   - prune_log2 (last argument of every entry point that writes a gradient):
+ *     the gradient pass writes an element as exact zero without computing it
+ *     when it can bound its magnitude by grad_scale * 2^prune_log2 from the
+ *     lattice state alone (see rnnt_mi355x_set_prune_log2).  Accepted:
+ *     [-inf, -16]; -inf computes every element; NaN (the C macro NAN) = the
+ *     process default.  A per-call input: concurrent calls with different
+ *     thresholds do not affect each other;
  *   - every function returns an rnnt_mi355x_status; nothing throws or aborts.
  *
  * Limits: 1 <= maxU1 <= 1024, B*maxT*maxU1 < 2^31, (maxT+2)*maxU1 < 2^28,
@@ -81,12 +89,12 @@ int rnnt_mi355x_forward(const float* logits, const int32_t* labels, const int32_
  * pass. */
 int rnnt_mi355x_backward(const float* logits, float* grad, const int32_t* labels, const int32_t* in_len,
                          const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank, const float* grad_scale,
-                         void* workspace, void* hip_stream);
+                         void* workspace, void* hip_stream, float prune_log2);
 
 /* Same, overwriting the logits with their gradient. */
 int rnnt_mi355x_backward_inplace(float* logits_inout, const int32_t* labels, const int32_t* in_len,
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
-                                 const float* grad_scale, void* workspace, void* hip_stream);
+                                 const float* grad_scale, void* workspace, void* hip_stream, float prune_log2);
 
 /* rnnt_mi355x_forward / rnnt_mi355x_backward on tensors whose utterances are
  * `*_batch_stride` ELEMENTS apart (>= maxT*maxU1*V; inside an utterance the
@@ -101,7 +109,7 @@ int rnnt_mi355x_forward_strided(const float* logits, size_t logits_batch_stride,
 int rnnt_mi355x_backward_strided(const float* logits, size_t logits_batch_stride, float* grad,
                                  size_t grad_batch_stride, const int32_t* labels, const int32_t* in_len,
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
-                                 const float* grad_scale, void* workspace, void* hip_stream);
+                                 const float* grad_scale, void* workspace, void* hip_stream, float prune_log2);
 
 /* The crop itself as an argument: logits_full / grad_full are dense
  * [B, T0, maxU1, V] tensors and the lattice uses frames t_offset .. T0-1 of every
@@ -118,13 +126,13 @@ int rnnt_mi355x_forward_cropped(const float* logits_full, const int32_t* labels,
 int rnnt_mi355x_backward_cropped(const float* logits_full, float* grad_full, const int32_t* labels,
                                  const int32_t* in_len, const int32_t* lab_len, int B, int T0, int t_offset,
                                  int maxU1, int V, int blank, const float* grad_scale, void* workspace,
-                                 void* hip_stream);
+                                 void* hip_stream, float prune_log2);
 
 /* forward + backward_inplace in one call: what one training step of
  * reference rnnt/train.py:151-157 spends in the loss layer. */
 int rnnt_mi355x_loss_grad(float* logits_inout, const int32_t* labels, const int32_t* in_len, const int32_t* lab_len,
                           int B, int maxT, int maxU1, int V, int blank, const float* grad_scale, float* costs,
-                          void* workspace, void* hip_stream);
+                          void* workspace, void* hip_stream, float prune_log2);
 
 /* rnnt_mi355x_loss_grad with optional hipEvent_t handles recorded on
  * `hip_stream` around its kernels: events4[0] before the log-sum-exp pass,
@@ -135,7 +143,7 @@ int rnnt_mi355x_loss_grad(float* logits_inout, const int32_t* labels, const int3
 int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, const int32_t* in_len,
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
                                  const float* grad_scale, float* costs, void* workspace, void* hip_stream,
-                                 void* const* events4);
+                                 float prune_log2, void* const* events4);
 
 /* rnnt_mi355x_loss_grad for callers that cannot allocate or own device
  * scratch memory: code under HIP graph capture, tight serving loops, harnesses
@@ -158,7 +166,7 @@ int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, con
 int rnnt_mi355x_loss_grad_static(float* logits_inout, const int32_t* labels, const int32_t* in_len,
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
                                  const float* grad_scale, float* costs, double* scalars2, int32_t* flags_out,
-                                 void* hip_stream);
+                                 void* hip_stream, float prune_log2);
 
 /* ---- fused additive joint ------------------------------------------------
  * The loss of the reference's additive-joint model, Util.rnnt_lambda_func
@@ -181,7 +189,7 @@ int rnnt_mi355x_joint_forward(const float* f, size_t f_batch_stride, const float
 int rnnt_mi355x_joint_backward(const float* f, size_t f_batch_stride, const float* g, const int32_t* labels,
                                const int32_t* in_len, const int32_t* lab_len, int B, int maxT, int maxU1, int V,
                                int blank, const float* grad_scale, float* df, size_t df_batch_stride, float* dg,
-                               void* workspace, void* hip_stream);
+                               void* workspace, void* hip_stream, float prune_log2);
 
 /* ---- first layer of the fully-connected joint --------------------------------
  * The reference's FC-joint model tiles the encoder output [B,T,He] and the
@@ -239,19 +247,31 @@ int rnnt_mi355x_joint_log_softmax(const float* f, int f_rows, const float* g, in
  * clipnorm needs (reference keras_model.py:209-213). */
 int rnnt_mi355x_reduce_scalars(const float* costs, int B, void* workspace, double* out2, void* hip_stream);
 
-/* The gradient kernels skip lattice cells whose occupancy
- * gamma = P(path through (t,u) | labels) is below 2^log2_threshold: every
- * element of such a row's gradient is bounded by grad_scale*gamma, so the row
- * is written as exact zeros and its logits are not read a second time.
- * Default -28 (3.7e-9); accepted range [-inf, -16] (-inf: nothing is pruned).
- * Process-wide; takes effect for backward calls enqueued afterwards.  A
- * tuning knob without counterpart in the reference (whose dependency computes
- * every element). */
+/* Pruning of the gradient pass.  With gamma = P(path through (t,u) | labels)
+ * the occupancy of a lattice cell, p(v) the softmax of its row and p_max the
+ * largest of them, the gradient of the row is grad_scale * (gamma*p(v) - the
+ * blank's / the label's transition probability at those two v).  Every element
+ * is bounded by grad_scale*gamma, and every element except the blank's and
+ * the label's by grad_scale*gamma*p_max.  With T = 2^log2_threshold:
+ *   gamma < T            the whole row is written as exact zeros;
+ *   gamma*p_max < T      (diffuse posteriors) the row is written as exact
+ *                        zeros except its blank and label entries, which are
+ *                        written exactly from the lattice state alone;
+ * in both cases the row's logits are not read a second time, and no element
+ * written as zero exceeds grad_scale*T in magnitude.  The fused additive joint
+ * applies the first rule only (it reads nothing twice: pruned cells are left
+ * out of its contractions), the kernels for V <= 128 whose rows are no
+ * multiple of 16 bytes likewise.  Default -28 (T = 3.7e-9); accepted range
+ * [-inf, -16] (-inf: every element is computed).  This sets the process-wide
+ * default that calls passing NaN as their prune_log2 use; it takes effect for
+ * calls made afterwards.  A tuning knob without counterpart in the reference
+ * (whose dependency computes every element). */
 int rnnt_mi355x_set_prune_log2(float log2_threshold);
 float rnnt_mi355x_get_prune_log2(void);
 
 /* *host_cells = lattice cells the last backward on this workspace visited,
- * *host_pruned = how many of them fell below the pruning threshold.  Runs a
+ * *host_pruned = how many of their rows were not read a second time (pruned or
+ * sparse, see rnnt_mi355x_set_prune_log2).  Runs a
  * small kernel and waits for the stream.  A measurement aid without
  * counterpart in the reference. */
 int rnnt_mi355x_read_stats(void* workspace, uint64_t* host_cells, uint64_t* host_pruned, void* hip_stream);

@@ -22,31 +22,43 @@ BAD_INPUT_DATA = 4
 FLAG_BAD_LENGTH = 1
 FLAG_BAD_LABEL = 2
 DEFAULT_PRUNE_LOG2 = -28.0  # kPruneLog2 of csrc/workspace.h
+USE_DEFAULT_PRUNE = float("nan")  # prune_log2 argument meaning "the process default of rnnt_mi355x_set_prune_log2"
+
+
+def prune_arg(prune_log2) -> float:
+    """The prune_log2 argument of the C entry points for a Python-side value
+    (None = the process default)."""
+    if prune_log2 is None:
+        return USE_DEFAULT_PRUNE
+    v = float(prune_log2)
+    if not v <= -16.0:  # also refuses NaN: the default is spelled None here
+        raise ValueError("prune_log2 must lie in [-inf, -16]")
+    return v
 STATIC_WORKSPACE_BYTES = 32 << 20  # RNNT_MI355X_STATIC_WORKSPACE_BYTES
 
 _lib = None
 
-_vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
+_vp, _i, _sz, _ll, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong, ctypes.c_float
 _META = [_i] * 5  # B, maxT, maxU1, V, blank
 
 _SIGNATURES = {
     "rnnt_mi355x_workspace_bytes": (ctypes.c_int, [_i, _i, _i, ctypes.POINTER(_sz)]),
     "rnnt_mi355x_forward": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp]),
-    "rnnt_mi355x_backward": (ctypes.c_int, [_vp] * 5 + _META + [_vp, _vp, _vp]),
+    "rnnt_mi355x_backward": (ctypes.c_int, [_vp] * 5 + _META + [_vp, _vp, _vp, _f]),
     "rnnt_mi355x_forward_strided": (ctypes.c_int, [_vp, _sz] + [_vp] * 3 + _META + [_vp, _vp, _vp]),
-    "rnnt_mi355x_backward_strided": (ctypes.c_int, [_vp, _sz, _vp, _sz] + [_vp] * 3 + _META + [_vp, _vp, _vp]),
+    "rnnt_mi355x_backward_strided": (ctypes.c_int, [_vp, _sz, _vp, _sz] + [_vp] * 3 + _META + [_vp, _vp, _vp, _f]),
     "rnnt_mi355x_forward_cropped": (ctypes.c_int, [_vp] * 4 + [_i] * 6 + [_vp, _vp, _vp]),
-    "rnnt_mi355x_backward_cropped": (ctypes.c_int, [_vp] * 5 + [_i] * 6 + [_vp, _vp, _vp]),
-    "rnnt_mi355x_backward_inplace": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp]),
-    "rnnt_mi355x_loss_grad": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp]),
-    "rnnt_mi355x_loss_grad_events": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
-    "rnnt_mi355x_loss_grad_static": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp, _vp]),
+    "rnnt_mi355x_backward_cropped": (ctypes.c_int, [_vp] * 5 + [_i] * 6 + [_vp, _vp, _vp, _f]),
+    "rnnt_mi355x_backward_inplace": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _f]),
+    "rnnt_mi355x_loss_grad": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp, _f]),
+    "rnnt_mi355x_loss_grad_events": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp, _f, ctypes.POINTER(_vp)]),
+    "rnnt_mi355x_loss_grad_static": (ctypes.c_int, [_vp] * 4 + _META + [_vp, _vp, _vp, _vp, _vp, _f]),
     "rnnt_mi355x_set_prune_log2": (ctypes.c_int, [ctypes.c_float]),
     "rnnt_mi355x_get_prune_log2": (ctypes.c_float, []),
     "rnnt_mi355x_read_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), _vp]),
     "rnnt_mi355x_joint_workspace_bytes": (ctypes.c_int, [_i, _i, _i, _i, ctypes.POINTER(_sz)]),
     "rnnt_mi355x_joint_forward": (ctypes.c_int, [_vp, _sz] + [_vp] * 4 + _META + [_vp, _vp, _vp]),
-    "rnnt_mi355x_joint_backward": (ctypes.c_int, [_vp, _sz] + [_vp] * 4 + _META + [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "rnnt_mi355x_joint_backward": (ctypes.c_int, [_vp, _sz] + [_vp] * 4 + _META + [_vp, _vp, _sz, _vp, _vp, _vp, _f]),
     "rnnt_mi355x_fc_joint_workspace_bytes": (ctypes.c_int, [_i, _i, _i, _i, ctypes.POINTER(_sz)]),
     "rnnt_mi355x_fc_joint_forward": (ctypes.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rnnt_mi355x_fc_joint_backward": (ctypes.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

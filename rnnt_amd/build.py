@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = [os.path.join(CSRC, "rnnt_mi355x.hip"), os.path.join(CSRC, "fc_joint.hip"),
            os.path.join(CSRC, "skinny_dense.hip"), os.path.join(CSRC, "decode_step.hip")]
 # rnnt_mi355x.hip is one translation unit whose kernels live in these included pieces
-PIECES = [os.path.join(CSRC, n) for n in ("workspace.h", "device_util.h", "lse_rows.h", "sweep.h", "grad_rows.h", "grad_span.h", "grad_flat.h", "lse_span.h",
+PIECES = [os.path.join(CSRC, n) for n in ("workspace.h", "device_util.h", "lse_rows.h", "sweep.h", "grad_rows.h", "grad_span.h", "grad_split.h", "cell_coef.h", "grad_flat.h", "lse_span.h",
                                           "small_vocab.h", "joint.h", "aux_kernels.h")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rnnt_mi355x.h")
 LIB = os.path.join(CSRC, "librnnt_mi355x.so")

@@ -22,6 +22,9 @@ __global__ __launch_bounds__(64) void k_init(Ws w, int n_partial) {
     w.hdr->flags = 0;
     w.hdr->n_fallback = 0;
     w.hdr->n_partial = n_partial;
+    w.hdr->n_count = n_partial;
+    w.hdr->n_items_ready = 0;
+    w.hdr->items_ctr = 0ull;
     w.hdr->partial_off = w.partial_off;
     w.hdr->count_off = w.count_off;
     w.hdr->n_cells = 0;
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(1024) void k_reduce_counts(char* ws_base) {
   __shared__ unsigned long long sh[2][1024];
   Header* hdr = reinterpret_cast<Header*>(ws_base);
   const uint2* pc = reinterpret_cast<const uint2*>(ws_base + hdr->count_off);
-  const int n = hdr->n_partial;
+  const int n = hdr->n_count;
   unsigned long long c = 0, p = 0;
   for (int i = threadIdx.x; i < n; i += 1024) {
     const uint2 v = pc[i];

@@ -8,6 +8,7 @@
 
 #include "workspace.h"
 #include "device_util.h"
+#include "cell_coef.h"
 
 namespace {
 
@@ -86,25 +87,15 @@ __global__ __launch_bounds__(kFlatWaves * 64) __attribute__((amdgpu_waves_per_eu
         const size_t ci = plane + (size_t)(t + u) * U1s + u;
         const size_t ci_t = (t + u + 1 < w.D) ? ci + U1s : ci;
         const size_t ci_u = (u + 1 < U1s) ? ci_t + 1 : ci_t;
-        const double al = w.alpha[ci], be = w.beta[ci], be_t = w.beta[ci_t], be_u = w.beta[ci_u];
-        const float4 rc = w.rec[((size_t)b * (gm.maxT + 2) + 1 + t) * maxU1 + u];  // {lpb, lpl, lse, -}
+        CellRaw raw;
+        raw.a = w.alpha[ci]; raw.be = w.beta[ci]; raw.be_t = w.beta[ci_t]; raw.be_u = w.beta[ci_u];
+        raw.ll = ll2;
+        raw.rc = w.rec[((size_t)b * (gm.maxT + 2) + 1 + t) * maxU1 + u];  // {lpb, lpl, lse, log2 p_max}
         int lab = 0;
         if (maxU1 > 1) lab = labels[(size_t)b * (maxU1 - 1) + min(u, maxU1 - 2)];
-        const double a_ll = al - ll2;
-        const float g2 = (float)(a_ll + be);  // log2 gamma
-        if (is_cell && g2 >= gm.prune_log2) {
-          float e_b = -INFINITY;  // 2^-inf = 0: no blank move out of this cell
-          if (t < T - 1) e_b = (float)(a_ll + be_t) + rc.x;
-          else if (u == U) e_b = (float)a_ll + rc.x;
-          float plv = 0.f;
-          if (u < U) {
-            lab = (lab < 0 || lab >= V) ? 0 : lab;
-            plv = fast_exp2((float)(a_ll + be_u) + rc.y);
-          } else {
-            lab = -1;
-          }
-          cf = make_float4(g2 - rc.z, fast_exp2(e_b), plv, __int_as_float(lab));
-        }
+        raw.lab = (lab < 0 || lab >= V) ? 0 : lab;
+        raw.flags = cell_flags(is_cell, t, u, T, U);
+        cf = cell_coef<kSparseRows>(raw, gm.prune_log2, blank);
       }
       coef_s[i] = cf;
       // a row that straddles two blocks is counted by the block that holds its first chunk
@@ -114,7 +105,7 @@ __global__ __launch_bounds__(kFlatWaves * 64) __attribute__((amdgpu_waves_per_eu
     }
     if (lane == 0) { cnt_s[0][wv] = n_cell; cnt_s[1][wv] = n_pruned; }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) w.hdr->n_partial = gm.nblocks_all;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { w.hdr->n_partial = gm.nblocks_all; w.hdr->n_count = gm.nblocks_all; }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint2 c = make_uint2(0u, 0u);
@@ -186,6 +177,13 @@ __global__ __launch_bounds__(kFlatWaves * 64) __attribute__((amdgpu_waves_per_eu
               sqsum = __builtin_fmaf(gv, gv, sqsum);
               o[q] = gv;
             }
+          } else if ((pb != 0.f) | (pl != 0.f)) {  // sparse row: only the blank's and the label's entry are not negligible
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float gv = unread_elem(col + q, blank, lab, pb, pl, sc);
+              sqsum = __builtin_fmaf(gv, gv, sqsum);
+              o[q] = gv;
+            }
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[q] = 0.f;
@@ -204,6 +202,9 @@ __global__ __launch_bounds__(kFlatWaves * 64) __attribute__((amdgpu_waves_per_eu
               gv -= (e == blank) ? pb : 0.f;
               gv -= (e == lab) ? pl : 0.f;
               gv *= sc;
+              sqsum = __builtin_fmaf(gv, gv, sqsum);
+            } else if ((pb != 0.f) | (pl != 0.f)) {
+              gv = unread_elem(e, blank, lab, pb, pl, sc);
               sqsum = __builtin_fmaf(gv, gv, sqsum);
             }
             o[q] = gv;
@@ -230,6 +231,9 @@ __global__ __launch_bounds__(kFlatWaves * 64) __attribute__((amdgpu_waves_per_eu
       gv -= (e == blank) ? cf.y : 0.f;
       gv -= (e == __float_as_int(cf.w)) ? cf.z : 0.f;
       gv *= sc;
+      sqsum = __builtin_fmaf(gv, gv, sqsum);
+    } else if ((cf.y != 0.f) | (cf.z != 0.f)) {
+      gv = unread_elem(e, blank, __float_as_int(cf.w), cf.y, cf.z, sc);
       sqsum = __builtin_fmaf(gv, gv, sqsum);
     }
     gblk[off] = gv;

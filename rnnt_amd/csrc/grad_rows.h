@@ -6,6 +6,7 @@
 
 #include "workspace.h"
 #include "device_util.h"
+#include "cell_coef.h"
 
 namespace {
 
@@ -15,9 +16,9 @@ namespace {
 //   c2 = log2 gamma - lse,  pb = P(blank move | labels),  pl = P(label move | labels)
 // Same block/tile decomposition and two-deep pipeline as k_lse.  A block first
 // folds alpha, beta, the likelihood and the records of its cells into
-// {c2, pb, pl, label} in LDS; rows that hold no lattice cell, or whose
-// occupancy gamma is negligible, are marked inactive there and are zero-filled
-// without being read.  Blocks are taken in the reverse of k_lse's order so
+// {c2, pb, pl, label} in LDS (cell_coef.h); rows that hold no lattice cell, or
+// whose elements are all negligible, are marked inactive there and are
+// zero-filled without being read (sparse rows: plus their two exact entries).  Blocks are taken in the reverse of k_lse's order so
 // that the rows k_lse read last (still in the memory-side cache) are re-read
 // first.
 // ---------------------------------------------------------------------------
@@ -86,22 +87,19 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(RNNT_
       const bool is_cell = t < T && u <= U;
       if (is_cell) {
         const size_t ci = plane + (size_t)(t + u) * U1s + u;
-        const double a_ll = w.alpha[ci] - ll2;
-        const float4 rc = w.rec[((size_t)b * (gm.maxT + 2) + 1 + t) * maxU1 + u];  // {lpb, lpl, lse, -}
-        const float g2 = (float)(a_ll + w.beta[ci]);   // log2 gamma
-        if (g2 >= gm.prune_log2) {
-          float e_b = -INFINITY;  // 2^-inf = 0: no blank move out of this cell
-          if (t < T - 1) e_b = (float)(a_ll + w.beta[ci + U1s]) + rc.x;
-          else if (u == U) e_b = (float)a_ll + rc.x;
-          float plv = 0.f;
-          int lab = -1;
-          if (u < U) {
-            lab = labels[(size_t)b * (maxU1 - 1) + u];
-            lab = (lab < 0 || lab >= V) ? 0 : lab;
-            plv = fast_exp2((float)(a_ll + w.beta[ci + U1s + 1]) + rc.y);
-          }
-          cf = make_float4(g2 - rc.z, fast_exp2(e_b), plv, __int_as_float(lab));
+        CellRaw raw;
+        raw.a = w.alpha[ci]; raw.be = w.beta[ci]; raw.ll = ll2;
+        raw.be_t = (t < T - 1) ? w.beta[ci + U1s] : 0.0;
+        raw.rc = w.rec[((size_t)b * (gm.maxT + 2) + 1 + t) * maxU1 + u];  // {lpb, lpl, lse, log2 p_max}
+        raw.be_u = 0.0;
+        raw.lab = -1;
+        if (u < U) {
+          raw.be_u = w.beta[ci + U1s + 1];
+          const int lab = labels[(size_t)b * (maxU1 - 1) + u];
+          raw.lab = (lab < 0 || lab >= V) ? 0 : lab;
         }
+        raw.flags = cell_flags(true, t, u, T, U);
+        cf = cell_coef<kSparseRows>(raw, gm.prune_log2, blank);
       }
       coef_s[i] = cf;
       n_cell += __popcll(__ballot(is_cell));
@@ -109,7 +107,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(RNNT_
     }
     if (lane == 0) { cnt_s[0][wv] = n_cell; cnt_s[1][wv] = n_pruned; }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) w.hdr->n_partial = gm.nblocks_all;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { w.hdr->n_partial = gm.nblocks_all; w.hdr->n_count = gm.nblocks_all; }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint2 c = make_uint2(0u, 0u);
@@ -132,7 +130,7 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(RNNT_
       tl.rho[g] = in_blk ? cur.rho[g] : -1;
       tl.coef[g] = coef_s[rho];
       const bool active = in_blk & (tl.coef[g].x > -INFINITY);
-      if (!active) tl.coef[g].x = -INFINITY;
+      if (!in_blk) tl.coef[g] = make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
       const float* rp = xblk + (size_t)rho * V;
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
@@ -174,8 +172,17 @@ __global__ __launch_bounds__(kRowBlock) __attribute__((amdgpu_waves_per_eu(RNNT_
             if constexpr (RNNT_GRAD_STORE_PLAIN) store_vec_plain<VEC>(gp + (size_t)c * VEC, o);
             else store_vec<VEC>(gp + (size_t)c * VEC, o);
           } else {
+            if ((pb != 0.f) | (pl != 0.f)) {  // sparse row: only the blank's and the label's entry are not negligible
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) o[q] = 0.f;
+              for (int q = 0; q < VEC; ++q) {
+                const float gv = unread_elem(c * VEC + q, blank, lab, pb, pl, sc);
+                sqsum = __builtin_fmaf(gv, gv, sqsum);
+                o[q] = gv;
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < VEC; ++q) o[q] = 0.f;
+            }
             if constexpr (RNNT_GRAD_ZERO_PLAIN) store_vec_plain<VEC>(gp + (size_t)c * VEC, o);
             else store_vec<VEC>(gp + (size_t)c * VEC, o);
           }

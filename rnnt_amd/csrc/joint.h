@@ -40,6 +40,7 @@ struct JointGeom {
   int B, maxT, maxU1, V, blank;
   size_t fstride;  // elements between utterances of f (>= maxT*V): lets f be a crop along T of a larger tensor
   size_t dfstride; // same for d f
+  float prune_log2 = kPruneLog2;  // cells whose occupancy is below 2^prune_log2 are left out of the gradient (backward only)
 };
 
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -79,6 +80,9 @@ __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f,
     w.hdr->flags = 0;
     w.hdr->n_fallback = 0;
     w.hdr->n_partial = 0;
+    w.hdr->n_count = 0;
+    w.hdr->n_items_ready = 0;
+    w.hdr->items_ctr = 0ull;
     w.hdr->partial_off = w.partial_off;
     w.hdr->count_off = w.count_off;
     w.hdr->n_cells = 0;
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(256) void k_joint_coef(const int32_t* __restrict__ 
     int T, U;
     utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
     const CellRaw raw = cell_load(w, labels, b, t, u, T, U, jg.maxT, jg.maxU1, jg.V, true);
-    float4 cf = cell_coef(raw, kPruneLog2);  // nothing is re-read here: the fixed default
+    float4 cf = cell_coef<false>(raw, jg.prune_log2, jg.blank);  // (the record's fourth entry is this path's fallback flag)
     const float sc = grad_scale ? grad_scale[b] : 1.f;
     cf.y *= sc;
     cf.z *= sc;

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kRowBlock) void k_lse(const float* __restrict__ x, 
         const float m2 = m_run[g] * kLog2e, ls = fast_log2(s_all);
         if (tl.rho[g] >= 0 && j == 0)
           recs[tl.rho[g]] = make_float4(__builtin_fmaf(exb[g], kLog2e, -m2) - ls,
-                                        tl.haslab[g] ? __builtin_fmaf(exl[g], kLog2e, -m2) - ls : kNegF, m2 + ls, 0.f);
+                                        tl.haslab[g] ? __builtin_fmaf(exl[g], kLog2e, -m2) - ls : kNegF, m2 + ls, -ls);
       }
     }
   };

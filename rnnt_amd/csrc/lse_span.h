@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kLseWaves * 64) void k_lse_span(const float* __rest
       float4 rc = make_float4(kNegF, kNegF, 0.f, 0.f);
       if (state[g])
         rc = make_float4(__builtin_fmaf(xb[g], kLog2e, -m2) - ls,
-                         state[g] == 2 ? __builtin_fmaf(xl, kLog2e, -m2) - ls : kNegF, m2 + ls, 0.f);
+                         state[g] == 2 ? __builtin_fmaf(xl, kLog2e, -m2) - ls : kNegF, m2 + ls, -ls);
       recs[rho] = rc;
     }
   }

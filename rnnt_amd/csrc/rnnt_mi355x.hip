@@ -27,6 +27,7 @@
 // included below:
 //   workspace.h      constants, workspace header and layout
 //   device_util.h    exp2/log2, vector loads, DPP reductions, row cursor
+//   cell_coef.h      a cell's gradient coefficients {c2, pb, pl, label}; full / sparse / pruned rows
 //   lse_span.h       k_lse_span (aligned rows <= 4096)
 //   lse_rows.h       k_lse                 grad_rows.h   k_grad (any row)   grad_span.h  k_grad_span (aligned rows <= 4096)
 //   sweep.h          k_sweep               small_vocab.h V <= 128 variants of both passes
@@ -40,10 +41,12 @@
 
 #include "workspace.h"
 #include "device_util.h"
+#include "cell_coef.h"
 #include "lse_rows.h"
 #include "sweep.h"
 #include "grad_rows.h"
 #include "grad_span.h"
+#include "grad_split.h"
 #include "grad_flat.h"
 #include "lse_span.h"
 #include "small_vocab.h"
@@ -59,9 +62,20 @@ namespace {
 // host side
 // ---------------------------------------------------------------------------
 
-// Pruning threshold of the gradient kernels (log2 of the occupancy below which a row is zero-filled unread):
-// the library's one process-wide setting, see rnnt_mi355x_set_prune_log2.
+// Default pruning threshold of the gradient kernels (cell_coef.h) for calls that pass NaN as theirs: the library's one
+// process-wide setting, see rnnt_mi355x_set_prune_log2.
 std::atomic<float> g_prune_log2{kPruneLog2};
+
+// The threshold a call runs with: its own argument, or the process default when that is NaN.
+int resolve_prune(float arg, float* out) {
+  if (arg != arg) {
+    *out = g_prune_log2.load(std::memory_order_relaxed);
+    return RNNT_MI355X_OK;
+  }
+  if (!(arg <= -16.f)) return RNNT_MI355X_INVALID_VALUE;
+  *out = arg;
+  return RNNT_MI355X_OK;
+}
 
 struct RowCfg {
   int vec, L, nc, g;
@@ -105,7 +119,7 @@ RowCfg pick_row_cfg(int B, int maxT, int maxU1, int V, int blank, const void* p0
   c.gm.nTB = (maxT + TT - 1) / TT;
   c.gm.npass = (cpl + c.nc - 1) / c.nc;
   c.gm.b0 = 0;
-  c.gm.prune_log2 = g_prune_log2.load(std::memory_order_relaxed);
+  c.gm.prune_log2 = kPruneLog2;  // (the caller sets the threshold of its call)
   c.gm.xstride = c.gm.gstride = (size_t)maxT * maxU1 * V;
   c.gm.nblocks = B * c.gm.nTB;
   c.gm.nblocks_all = B * c.gm.nTB;
@@ -144,6 +158,15 @@ int check_shape(int B, int maxT, int maxU1, int V, int blank) {
   return RNNT_MI355X_OK;
 }
 
+// compute units of the current device (a resident grid is sized from it)
+int compute_units() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+    n = 256;
+  return n;
+}
+
 int launch_status() { return hipGetLastError() == hipSuccess ? RNNT_MI355X_OK : RNNT_MI355X_LAUNCH_FAILURE; }
 
 struct Call {
@@ -158,6 +181,7 @@ struct Call {
                             // frame 0 is logits - t_off*maxU1*V (and grad likewise); 0 = no such promise
   const float* grad_scale;
   float* costs;
+  float prune_log2 = kPruneLog2;  // threshold of this call's gradient pass
   Ws w;
 };
 
@@ -167,6 +191,7 @@ RowCfg sub_cfg(const Call& c, const void* p1, int b0, int nb) {
   RowCfg cfg = pick_row_cfg(c.B, c.maxT, c.maxU1, c.V, c.blank, c.logits, reinterpret_cast<const void*>(align_bits));
   cfg.gm.xstride = c.xstride;
   cfg.gm.gstride = c.gstride;
+  cfg.gm.prune_log2 = c.prune_log2;
   cfg.gm.b0 = b0;
   cfg.gm.nblocks = nb * cfg.gm.nTB;
   return cfg;
@@ -188,7 +213,7 @@ SmallGeom small_geom(const Call& c, int* blocks) {
   g.B = c.B; g.maxT = c.maxT; g.maxU1 = c.maxU1; g.V = c.V; g.blank = c.blank;
   g.frames = c.t_off + c.maxT; g.t_off = c.t_off;
   g.total_rows = (long long)c.B * g.frames * c.maxU1;
-  g.prune_log2 = g_prune_log2.load(std::memory_order_relaxed);
+  g.prune_log2 = c.prune_log2;
   g.ntiles_full = (int)(g.total_rows / 64);
   long long want = (g.ntiles_full + kSmallWaves - 1) / kSmallWaves;
   // persistent grid, exactly one resident round: tiles are dealt round-robin to the waves.  Residency per CU is
@@ -261,7 +286,7 @@ SpanGeom span_geom(const Call& c, int b0) {
   sg.rows_utt = c.maxT * c.maxU1;
   sg.nchunks = sg.nblocks = sg.nblocks_all = 0;  // set per kernel: they depend on its rows per block
   sg.b0 = b0;
-  sg.prune_log2 = g_prune_log2.load(std::memory_order_relaxed);
+  sg.prune_log2 = c.prune_log2;
   sg.xstride = c.xstride; sg.gstride = c.gstride;
   return sg;
 }
@@ -344,7 +369,7 @@ void launch_flat(const Call& c, int b0, int nb, hipStream_t st) {
   fg.blocks_utt = (int)((total + per_block - 1) / per_block);
   fg.table_rows = (int)(per_block / c.V) + 2;
   fg.b0 = b0; fg.nblocks = nb * fg.blocks_utt; fg.nblocks_all = c.B * fg.blocks_utt;
-  fg.prune_log2 = g_prune_log2.load(std::memory_order_relaxed);
+  fg.prune_log2 = c.prune_log2;
   fg.xstride = c.xstride; fg.gstride = c.gstride;
   const dim3 grid((unsigned)fg.nblocks), blk(kFlatWaves * 64);
   const size_t lds = sizeof(float4) * (size_t)fg.table_rows;
@@ -414,11 +439,52 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
       kernel<<<dim3((unsigned)sg.nblocks), dim3(kSpanWaves * 64), 0, st>>>(c.logits, c.grad, c.labels, c.in_len, c.lab_len,
                                                                           c.grad_scale, sg, c.w);
     };
-    if (nchunk <= 64) go(k_grad_span<16, 4, RNNT_SPAN_NG>, kSpanWaves * RNNT_SPAN_NG * 4);
-    else if (nchunk <= 128) go(k_grad_span<32, 4, RNNT_SPAN_NG>, kSpanWaves * RNNT_SPAN_NG * 2);
-    else if (nchunk <= 256) go(k_grad_span<64, 4, RNNT_SPAN_NG>, kSpanWaves * RNNT_SPAN_NG);
-    else if (nchunk <= 512) go(k_grad_span<64, 8, RNNT_SPAN_NG / 2>, kSpanWaves * (RNNT_SPAN_NG / 2));
-    else go(k_grad_span<64, 16, RNNT_SPAN_NG / 4>, kSpanWaves * (RNNT_SPAN_NG / 4));
+#ifndef RNNT_NO_SPLIT
+    // rows of whole KiB: classify, zero-fill and read-modify-write as three kernels (grad_split.h)
+    if (c.V % 256 == 0 && c.B <= 65535 && b0 == 0 && nb == c.B) {
+      SplitGeom sp;
+      sp.maxT = c.maxT; sp.maxU1 = c.maxU1; sp.V = c.V; sp.blank = c.blank;
+      sp.rows_utt = sg.rows_utt;
+      sp.regions_utt = ws_regions(c.maxT, c.maxU1);
+      sp.prune_log2 = c.prune_log2;
+      sp.xstride = c.xstride; sp.gstride = c.gstride;
+      const int ng = nchunk <= 256 ? RNNT_SPAN_NG : nchunk <= 512 ? RNNT_SPAN_NG / 2 : RNNT_SPAN_NG / 4;
+      sp.rb = kSpanWaves * ng;
+      sp.spb = (kRegionRows + sp.rb - 1) / sp.rb;
+      const dim3 per_region((unsigned)sp.regions_utt, (unsigned)c.B);
+      k_classify_rows<<<per_region, kClassifyBlock, 0, st>>>(c.labels, c.in_len, c.lab_len, c.grad_scale, sp, c.w);
+      // a resident grid: two blocks of six wavefronts per compute unit is what their registers allow
+      const long long max_items = (long long)c.B * sp.regions_utt * sp.spb;
+      const long long resident = 2LL * compute_units();
+      const unsigned grid_rmw = (unsigned)(max_items < resident ? max_items : resident);
+      const dim3 blk(kSpanWaves * 64);
+      auto rmw = [&]() {
+        if (nchunk <= 256) k_grad_rmw<4, RNNT_SPAN_NG><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
+        else if (nchunk <= 512) k_grad_rmw<8, RNNT_SPAN_NG / 2><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
+        else k_grad_rmw<16, RNNT_SPAN_NG / 4><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
+      };
+      const int row_kib = c.V / 256;
+      const long long kib_utt = (long long)sg.rows_utt * row_kib;  // < 2^31: rows < 2^31 / B and V <= 4096
+      auto fill = [&]() {
+        k_fill_rows<<<dim3((unsigned)((kib_utt + 3) / 4), (unsigned)c.B), 256, 0, st>>>(c.grad, c.gstride, (int)kib_utt, row_kib,
+                                                                                     c.w.rowbits, c.w.row_words);
+        k_patch_sparse<<<per_region, 256, 0, st>>>(c.grad, c.grad_scale, sp, c.w);
+      };
+#ifdef RNNT_SPLIT_FILL_FIRST
+      fill();
+      rmw();
+#else
+      rmw();
+      fill();
+#endif
+      return;
+    }
+#endif
+    if (nchunk <= 64) go(k_grad_span<16, 4, RNNT_SPAN_NG>, SpanShape<16, RNNT_SPAN_NG>::ROWS);
+    else if (nchunk <= 128) go(k_grad_span<32, 4, RNNT_SPAN_NG>, SpanShape<32, RNNT_SPAN_NG>::ROWS);
+    else if (nchunk <= 256) go(k_grad_span<64, 4, RNNT_SPAN_NG>, SpanShape<64, RNNT_SPAN_NG>::ROWS);
+    else if (nchunk <= 512) go(k_grad_span<64, 8, RNNT_SPAN_NG / 2>, SpanShape<64, RNNT_SPAN_NG / 2>::ROWS);
+    else go(k_grad_span<64, 16, RNNT_SPAN_NG / 4>, SpanShape<64, RNNT_SPAN_NG / 4>::ROWS);
     return;
   }
 #endif
@@ -462,10 +528,14 @@ int launch_loss_grad(const Call& c, hipStream_t st, void* const* ev) {
 
 int make_call(Call* c, const float* logits, float* grad, const int32_t* labels, const int32_t* in_len,
               const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank, const float* grad_scale,
-              float* costs, void* workspace, bool need_grad, bool need_costs, size_t xstride = 0, size_t gstride = 0,
-              int t_off = 0) {
-  const int rc = check_shape(B, maxT, maxU1, V, blank);
+              float* costs, void* workspace, bool need_grad, bool need_costs, float prune_log2, size_t xstride = 0,
+              size_t gstride = 0, int t_off = 0) {
+  int rc = check_shape(B, maxT, maxU1, V, blank);
   if (rc != RNNT_MI355X_OK) return rc;
+  if (need_grad) {
+    rc = resolve_prune(prune_log2, &c->prune_log2);
+    if (rc != RNNT_MI355X_OK) return rc;
+  }
   c->t_off = t_off;
   const size_t dense = (size_t)maxT * maxU1 * V;
   if ((xstride && xstride < dense) || (gstride && gstride < dense)) return RNNT_MI355X_INVALID_VALUE;
@@ -642,7 +712,18 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
 
 extern "C" {
 
-int rnnt_mi355x_version(void) { return 102; }
+int rnnt_mi355x_version(void) { return 200; }
+
+#ifdef RNNT_RMW_TIMING
+// experiment builds only: reads and clears the per-phase cycle sums of k_grad_rmw
+int rnnt_mi355x_debug_rmw_timing(unsigned long long* host8) {
+  if (hipDeviceSynchronize() != hipSuccess) return RNNT_MI355X_LAUNCH_FAILURE;
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_rmw_dbg), 64) != hipSuccess) return RNNT_MI355X_LAUNCH_FAILURE;
+  unsigned long long z[8] = {};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_rmw_dbg), z, 64) != hipSuccess) return RNNT_MI355X_LAUNCH_FAILURE;
+  return RNNT_MI355X_OK;
+}
+#endif
 
 int rnnt_mi355x_set_prune_log2(float log2_threshold) {
   if (!(log2_threshold <= -16.f)) return RNNT_MI355X_INVALID_VALUE;  // also rejects NaN
@@ -676,17 +757,17 @@ int rnnt_mi355x_forward(const float* logits, const int32_t* labels, const int32_
                         void* hip_stream) {
   Call c;
   const int rc = make_call(&c, logits, nullptr, labels, in_len, lab_len, B, maxT, maxU1, V, blank, nullptr, costs,
-                           workspace, false, true);
+                           workspace, false, true, 0.f);
   if (rc != RNNT_MI355X_OK) return rc;
   return launch_forward(c, static_cast<hipStream_t>(hip_stream));
 }
 
 int rnnt_mi355x_backward(const float* logits, float* grad, const int32_t* labels, const int32_t* in_len,
                          const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank, const float* grad_scale,
-                         void* workspace, void* hip_stream) {
+                         void* workspace, void* hip_stream, float prune_log2) {
   Call c;
   const int rc = make_call(&c, logits, grad, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale, nullptr,
-                           workspace, true, false);
+                           workspace, true, false, prune_log2);
   if (rc != RNNT_MI355X_OK) return rc;
   return launch_backward(c, static_cast<hipStream_t>(hip_stream));
 }
@@ -696,7 +777,7 @@ int rnnt_mi355x_forward_strided(const float* logits, size_t logits_batch_stride,
                                 int blank, float* costs, void* workspace, void* hip_stream) {
   Call c;
   const int rc = make_call(&c, logits, nullptr, labels, in_len, lab_len, B, maxT, maxU1, V, blank, nullptr, costs,
-                           workspace, false, true, logits_batch_stride, 0);
+                           workspace, false, true, 0.f, logits_batch_stride, 0);
   if (rc != RNNT_MI355X_OK) return rc;
   return launch_forward(c, static_cast<hipStream_t>(hip_stream));
 }
@@ -704,10 +785,10 @@ int rnnt_mi355x_forward_strided(const float* logits, size_t logits_batch_stride,
 int rnnt_mi355x_backward_strided(const float* logits, size_t logits_batch_stride, float* grad,
                                  size_t grad_batch_stride, const int32_t* labels, const int32_t* in_len,
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
-                                 const float* grad_scale, void* workspace, void* hip_stream) {
+                                 const float* grad_scale, void* workspace, void* hip_stream, float prune_log2) {
   Call c;
   const int rc = make_call(&c, logits, grad, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale, nullptr,
-                           workspace, true, false, logits_batch_stride, grad_batch_stride);
+                           workspace, true, false, prune_log2, logits_batch_stride, grad_batch_stride);
   if (rc != RNNT_MI355X_OK) return rc;
   return launch_backward(c, static_cast<hipStream_t>(hip_stream));
 }
@@ -720,7 +801,7 @@ int rnnt_mi355x_forward_cropped(const float* logits_full, const int32_t* labels,
   const size_t frame = (size_t)maxU1 * V, stride = (size_t)T0 * frame;
   Call c;
   const int rc = make_call(&c, logits_full + t_offset * frame, nullptr, labels, in_len, lab_len, B, T0 - t_offset,
-                           maxU1, V, blank, nullptr, costs, workspace, false, true, stride, stride, t_offset);
+                           maxU1, V, blank, nullptr, costs, workspace, false, true, 0.f, stride, stride, t_offset);
   if (rc != RNNT_MI355X_OK) return rc;
   return launch_forward(c, static_cast<hipStream_t>(hip_stream));
 }
@@ -728,39 +809,39 @@ int rnnt_mi355x_forward_cropped(const float* logits_full, const int32_t* labels,
 int rnnt_mi355x_backward_cropped(const float* logits_full, float* grad_full, const int32_t* labels,
                                  const int32_t* in_len, const int32_t* lab_len, int B, int T0, int t_offset,
                                  int maxU1, int V, int blank, const float* grad_scale, void* workspace,
-                                 void* hip_stream) {
+                                 void* hip_stream, float prune_log2) {
   if (t_offset < 0 || t_offset >= T0 || !logits_full || !grad_full) return RNNT_MI355X_INVALID_VALUE;
   if ((long long)B * T0 * maxU1 >= (1LL << 31)) return RNNT_MI355X_UNSUPPORTED_SIZE;
   const size_t frame = (size_t)maxU1 * V, stride = (size_t)T0 * frame;
   Call c;
   const int rc = make_call(&c, logits_full + t_offset * frame, grad_full + t_offset * frame, labels, in_len, lab_len,
-                           B, T0 - t_offset, maxU1, V, blank, grad_scale, nullptr, workspace, true, false, stride,
-                           stride, t_offset);
+                           B, T0 - t_offset, maxU1, V, blank, grad_scale, nullptr, workspace, true, false, prune_log2,
+                           stride, stride, t_offset);
   if (rc != RNNT_MI355X_OK) return rc;
   return launch_backward(c, static_cast<hipStream_t>(hip_stream));
 }
 
 int rnnt_mi355x_backward_inplace(float* logits_inout, const int32_t* labels, const int32_t* in_len,
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
-                                 const float* grad_scale, void* workspace, void* hip_stream) {
+                                 const float* grad_scale, void* workspace, void* hip_stream, float prune_log2) {
   return rnnt_mi355x_backward(logits_inout, logits_inout, labels, in_len, lab_len, B, maxT, maxU1, V, blank,
-                              grad_scale, workspace, hip_stream);
+                              grad_scale, workspace, hip_stream, prune_log2);
 }
 
 int rnnt_mi355x_loss_grad(float* logits_inout, const int32_t* labels, const int32_t* in_len, const int32_t* lab_len,
                           int B, int maxT, int maxU1, int V, int blank, const float* grad_scale, float* costs,
-                          void* workspace, void* hip_stream) {
+                          void* workspace, void* hip_stream, float prune_log2) {
   return rnnt_mi355x_loss_grad_events(logits_inout, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale,
-                                      costs, workspace, hip_stream, nullptr);
+                                      costs, workspace, hip_stream, prune_log2, nullptr);
 }
 
 int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, const int32_t* in_len,
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
                                  const float* grad_scale, float* costs, void* workspace, void* hip_stream,
-                                 void* const* events4) {
+                                 float prune_log2, void* const* events4) {
   Call c;
   const int rc = make_call(&c, logits_inout, logits_inout, labels, in_len, lab_len, B, maxT, maxU1, V, blank,
-                           grad_scale, costs, workspace, true, true);
+                           grad_scale, costs, workspace, true, true, prune_log2);
   if (rc != RNNT_MI355X_OK) return rc;
   return launch_loss_grad(c, static_cast<hipStream_t>(hip_stream), events4);
 }
@@ -768,7 +849,7 @@ int rnnt_mi355x_loss_grad_events(float* logits_inout, const int32_t* labels, con
 int rnnt_mi355x_loss_grad_static(float* logits_inout, const int32_t* labels, const int32_t* in_len,
                                  const int32_t* lab_len, int B, int maxT, int maxU1, int V, int blank,
                                  const float* grad_scale, float* costs, double* scalars2, int32_t* flags_out,
-                                 void* hip_stream) {
+                                 void* hip_stream, float prune_log2) {
   int rc = check_shape(B, maxT, maxU1, V, blank);
   if (rc != RNNT_MI355X_OK) return rc;
   if (ws_layout(nullptr, B, maxT, maxU1, nullptr) > (size_t)RNNT_MI355X_STATIC_WORKSPACE_BYTES)
@@ -778,7 +859,7 @@ int rnnt_mi355x_loss_grad_static(float* logits_inout, const int32_t* labels, con
   if (rc != RNNT_MI355X_OK) return rc;
   Call c;
   rc = make_call(&c, logits_inout, logits_inout, labels, in_len, lab_len, B, maxT, maxU1, V, blank, grad_scale, costs,
-                 ws, true, true);
+                 ws, true, true, prune_log2);
   if (rc != RNNT_MI355X_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   rc = launch_loss_grad(c, st, nullptr);
@@ -816,12 +897,14 @@ int rnnt_mi355x_joint_forward(const float* f, size_t f_batch_stride, const float
 int rnnt_mi355x_joint_backward(const float* f, size_t f_batch_stride, const float* g, const int32_t* labels,
                                const int32_t* in_len, const int32_t* lab_len, int B, int maxT, int maxU1, int V,
                                int blank, const float* grad_scale, float* df, size_t df_batch_stride, float* dg,
-                               void* workspace, void* hip_stream) {
+                               void* workspace, void* hip_stream, float prune_log2) {
   JointCall c;
-  const int rc = make_joint_call(&c, f, f_batch_stride, g, labels, in_len, lab_len, B, maxT, maxU1, V, blank,
-                                 df_batch_stride, workspace);
+  int rc = make_joint_call(&c, f, f_batch_stride, g, labels, in_len, lab_len, B, maxT, maxU1, V, blank,
+                           df_batch_stride, workspace);
   if (rc != RNNT_MI355X_OK) return rc;
   if (!df || !dg) return RNNT_MI355X_INVALID_VALUE;
+  rc = resolve_prune(prune_log2, &c.jg.prune_log2);
+  if (rc != RNNT_MI355X_OK) return rc;
   return launch_joint_backward(c, grad_scale, df, dg, static_cast<hipStream_t>(hip_stream));
 }
 

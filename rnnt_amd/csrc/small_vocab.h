@@ -6,6 +6,7 @@
 
 #include "workspace.h"
 #include "device_util.h"
+#include "cell_coef.h"
 
 namespace {
 
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
         }
         lpl = __builtin_fmaf(rowp[clab], kLog2e, -m2) - ls;
       }
-      rc = make_float4(__builtin_fmaf(rowp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, 0.f);
+      rc = make_float4(__builtin_fmaf(rowp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, -ls);
     }
     pb = cb; pt = ct; pu = cu; pin = cin; prc = rc;
   }
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_lse_small(const float* __restri
           }
           lpl = __builtin_fmaf(rp[lab], kLog2e, -m2) - ls;
         }
-        rc = make_float4(__builtin_fmaf(rp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, 0.f);
+        rc = make_float4(__builtin_fmaf(rp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, -ls);
       }
       small_write_record(w, g, b, t, u, rc);
     }
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(64) void k_lse_small_span(const float* __restrict__
           }
           lpl = __builtin_fmaf(rp[lab], kLog2e, -m2) - ls;
         }
-        rc = make_float4(__builtin_fmaf(rp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, 0.f);
+        rc = make_float4(__builtin_fmaf(rp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, -ls);
       }
       small_write_record(w, g, b, t, u, rc);
     }
@@ -329,21 +330,13 @@ __global__ __launch_bounds__(64) void k_lse_small_span(const float* __restrict__
         }
         lpl = __builtin_fmaf(rowp[lab], kLog2e, -m2) - ls;
       }
-      rc = make_float4(__builtin_fmaf(rowp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, 0.f);
+      rc = make_float4(__builtin_fmaf(rowp[g.blank], kLog2e, -m2) - ls, lpl, m2 + ls, -ls);
     }
   }
   if (in_range) small_write_record(w, g, b, t, u, rc);
 }
 
-// Everything the gradient of a row needs about its lattice cell, as loaded (no arithmetic yet, so that the
-// loads can be issued a tile ahead of their use).
-struct CellRaw {
-  double a, be, be_t, be_u, ll;
-  float4 rc;  // {lpb, lpl, lse, -}
-  int lab;
-  int flags;  // 1 lattice cell, 2 t < T-1, 4 u == U, 8 u < U
-};
-
+// The cell state of one row (CellRaw, cell_coef.h), loaded only where the row holds a lattice cell.
 __device__ __forceinline__ CellRaw cell_load(const Ws& w, const int32_t* labels, int b, int t, int u, int T, int U,
                                              int maxT, int maxU1, int V, bool in_range) {
   CellRaw r;
@@ -354,7 +347,7 @@ __device__ __forceinline__ CellRaw cell_load(const Ws& w, const int32_t* labels,
   if (in_range && t < T && u <= U) {
     const int U1s = w.U1s;
     const size_t ci = ((size_t)b * w.D + (t + u)) * U1s + u;
-    r.flags = 1 | (t < T - 1 ? 2 : 0) | (u == U ? 4 : 0) | (u < U ? 8 : 0);
+    r.flags = cell_flags(true, t, u, T, U);
     r.a = w.alpha[ci];
     r.be = w.beta[ci];
     r.ll = w.ll[b];
@@ -367,23 +360,6 @@ __device__ __forceinline__ CellRaw cell_load(const Ws& w, const int32_t* labels,
     }
   }
   return r;
-}
-
-// {c2, pb, pl, label} of the cell (c2 = -inf: the row's gradient is exactly zero)
-__device__ __forceinline__ float4 cell_coef(const CellRaw& r, float prune_log2) {
-  float4 cf = make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
-  if (r.flags & 1) {
-    const double a_ll = r.a - r.ll;
-    const float g2 = (float)(a_ll + r.be);  // log2 gamma
-    if (g2 >= prune_log2) {
-      float e_b = -INFINITY;  // 2^-inf = 0: no blank move out of this cell
-      if (r.flags & 2) e_b = (float)(a_ll + r.be_t) + r.rc.x;
-      else if (r.flags & 4) e_b = (float)a_ll + r.rc.x;
-      const float plv = (r.flags & 8) ? fast_exp2((float)(a_ll + r.be_u) + r.rc.y) : 0.f;
-      cf = make_float4(g2 - r.rc.z, fast_exp2(e_b), plv, __int_as_float(r.lab));
-    }
-  }
-  return cf;
 }
 
 template <int VEC>
@@ -431,7 +407,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
   const int gw = blockIdx.x * kSmallWaves + wv, nw = gridDim.x * kSmallWaves;
   const f4v* x4 = reinterpret_cast<const f4v*>(x);
   f4v* g4 = reinterpret_cast<f4v*>(grad);
-  if (blockIdx.x == 0 && threadIdx.x == 0) w.hdr->n_partial = gridDim.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { w.hdr->n_partial = gridDim.x; w.hdr->n_count = gridDim.x; }
   __shared__ int tail_cnt[2];  // cells / pruned cells of the last, partial tile (block 0 only)
   if (threadIdx.x < 2) tail_cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -467,8 +443,8 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
   float sqsum = 0.f;
   int n_cell = 0, n_pruned = 0;  // wave-uniform counts of lattice cells seen / pruned
   auto count = [&](const CellRaw& r, const float4& c) {
-    n_cell += __popcll(__ballot(r.flags & 1));
-    n_pruned += __popcll(__ballot((r.flags & 1) && !(c.x > -INFINITY)));
+    n_cell += __popcll(__ballot(r.flags & kCellValid));
+    n_pruned += __popcll(__ballot((r.flags & kCellValid) && !(c.x > -INFINITY)));
   };
   // Tiles are taken in the reverse of k_lse_small's order (most recently read rows first).  Three stages are in
   // flight: the cell state of tile k+2, the logits of tile k+1 (gated by which of its rows are active) and the
@@ -482,7 +458,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
   raw.flags = 0;
   if (k < g.ntiles_full) {
     const CellRaw r0 = raw_of(last - k, sc);
-    cf = cell_coef(r0, g.prune_log2);
+    cf = cell_coef<false>(r0, g.prune_log2, g.blank);
     count(r0, cf);
     active = __ballot(cf.x > -INFINITY);
     issue(last - k, active);
@@ -498,7 +474,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
     const float4 ccf = cf;
     const float csc = sc;
     if (k + nw < g.ntiles_full) {
-      cf = cell_coef(raw, g.prune_log2);  // loaded one iteration ago
+      cf = cell_coef<false>(raw, g.prune_log2, g.blank);  // loaded one iteration ago
       count(raw, cf);
       sc = sc_raw;
       active = __ballot(cf.x > -INFINITY);
@@ -534,8 +510,8 @@ __global__ __launch_bounds__(kSmallBlock) void k_grad_small(const float* x, floa
     small_decode(row, g, in_len, lab_len, b, t, u, T, U, in_range);
     if (row < g.total_rows) {
       const CellRaw rl = cell_load(w, labels, b, t, u, T, U, g.maxT, g.maxU1, V, in_range);
-      const float4 c = cell_coef(rl, g.prune_log2);
-      if (rl.flags & 1) {  // divergent here: counted per lane, summed below
+      const float4 c = cell_coef<false>(rl, g.prune_log2, g.blank);
+      if (rl.flags & kCellValid) {  // divergent here: counted per lane, summed below
         atomicAdd(&tail_cnt[0], 1);
         if (!(c.x > -INFINITY)) atomicAdd(&tail_cnt[1], 1);
       }
@@ -592,7 +568,7 @@ __global__ __launch_bounds__(64) void k_grad_small_span(const float* x, float* g
   };
   const f4v* x4 = reinterpret_cast<const f4v*>(x);
   f4v* g4 = reinterpret_cast<f4v*>(grad);
-  if (blockIdx.x == 0 && lane == 0) w.hdr->n_partial = gridDim.x;
+  if (blockIdx.x == 0 && lane == 0) { w.hdr->n_partial = gridDim.x; w.hdr->n_count = gridDim.x; }
 
   // rows [row_lo(i), row_hi(i)] of a tile overlap its i-th KiB: that load is needed iff one of them is active
   auto chunk_needed = [&](unsigned long long active, int i) {
@@ -618,8 +594,8 @@ __global__ __launch_bounds__(64) void k_grad_small_span(const float* x, float* g
     bool cell = false, pruned = false;
     if (row < g.total_rows) {
       const CellRaw rl = cell_load(w, labels, b, t, u, T, U, g.maxT, g.maxU1, V, in_range);
-      const float4 c = cell_coef(rl, g.prune_log2);
-      cell = rl.flags & 1;
+      const float4 c = cell_coef<false>(rl, g.prune_log2, g.blank);
+      cell = rl.flags & kCellValid;
       pruned = cell && !(c.x > -INFINITY);
       float* gp = grad + (size_t)row * V;
       if (c.x > -INFINITY) {
@@ -660,11 +636,11 @@ __global__ __launch_bounds__(64) void k_grad_small_span(const float* x, float* g
     const bool ok = (Traw >= 1) & (Traw <= g.maxT) & (Uraw >= 0) & (Uraw <= g.maxU1 - 1);
     const int T = ok ? Traw : 0, U = ok ? Uraw : 0;
     const bool is_cell = in_range && t < T && u <= U;
-    r0.flags = is_cell ? (1 | (t < T - 1 ? 2 : 0) | (u == U ? 4 : 0) | (u < U ? 8 : 0)) : 0;
+    r0.flags = cell_flags(is_cell, t, u, T, U);
     r0.lab = (u < U) ? ((lab < 0 || lab >= V) ? 0 : lab) : -1;
-    const float4 cf = cell_coef(r0, g.prune_log2);
-    n_cell = __popcll(__ballot(r0.flags & 1));
-    n_pruned = __popcll(__ballot((r0.flags & 1) && !(cf.x > -INFINITY)));
+    const float4 cf = cell_coef<false>(r0, g.prune_log2, g.blank);
+    n_cell = __popcll(__ballot(r0.flags & kCellValid));
+    n_pruned = __popcll(__ballot((r0.flags & kCellValid) && !(cf.x > -INFINITY)));
     const unsigned long long active = __ballot(cf.x > -INFINITY);
     f4v* dst = g4 + (size_t)n * tile_f4;
     if (active == 0ull) {  // no active row: zeros straight to memory

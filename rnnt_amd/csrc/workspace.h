@@ -33,7 +33,12 @@ struct Header {
   uint64_t count_off;     // byte offset of `pcount` from the workspace base
   uint64_t n_cells;       // written by k_reduce_counts: lattice cells the last gradient pass visited ...
   uint64_t n_pruned;      // ... and how many of them it pruned
-  int32_t pad[52];
+  int32_t n_count;        // entries of `pcount` the last gradient pass wrote
+  int32_t n_items_ready;  // split gradient pass: work items of k_grad_rmw
+  // ... while k_classify_rows runs: low half = work items handed out so far, high half = blocks that have taken
+  // theirs (one atomic per block; zero between gradient passes)
+  unsigned long long items_ctr;
+  int32_t pad[48];
 };
 static_assert(sizeof(Header) == 256, "header is one 256-byte block");
 
@@ -53,6 +58,15 @@ struct Ws {
   // cells of a diagonal it owns as one contiguous run
   float2* lp2;
   int Dp;          // rows of lp2 per utterance = D rounded up to the sweep's band + one band
+  // Split gradient pass (k_classify_rows / k_fill_rows / k_grad_rmw, see grad_split.h).  An utterance's rows
+  // r = t*maxU1 + u are cut into regions of kRegionRows consecutive rows:
+  float4* crec;       // [B][regions][kRegionStride] {c2, pb, pl, (row in region) << 16 | label} (cell_coef.h): from the
+                      // front the region's full rows in row order, then entries that stand for nothing up to a whole
+                      // work item; from the end backwards its sparse rows
+  int* rcount;        // [B][regions] sparse rows of the region
+  int* items;         // work items of k_grad_rmw: (region id << 8) | block of entries inside the region's entries
+  uint32_t* rowbits;  // [B][row_words] bit r of an utterance set: row r is full (k_grad_rmw writes it, not k_fill_rows)
+  int row_words;      // 32-bit words of rowbits per utterance (rows rounded up to a multiple of 64)
   // fused additive joint only:
   float* mf2;      // [B][maxT]  max_v f(b,t,v) * log2(e)
   float* mg2;      // [B][maxU1] max_v g(b,u,v) * log2(e)
@@ -118,12 +132,20 @@ inline int joint_dg_split(int B, int Tp, int U1p, int Vp) {
 }
 
 // Slots of the per-block arrays `partial` / `pcount`: one per block of the gradient pass, whose blocks own
-// TT >= 1 frames (k_grad), a share of the rows (k_grad_small: fewer blocks than B*maxT) or at least kMinSpanRows
-// consecutive rows of an utterance (k_grad_span).
+// TT >= 1 frames (k_grad), a share of the rows (k_grad_small: fewer blocks than B*maxT), at least kMinSpanRows
+// consecutive rows of an utterance (k_grad_span) or at least kMinRmwRows entries of a region of kRegionRows rows
+// (k_grad_rmw).
 constexpr int kMinSpanRows = 8;
+constexpr int kRegionRows = 2048;
+constexpr int kRegionStride = kRegionRows + 64;  // entries of crec per region: its rows, padded up to a whole work item
+constexpr int kMinRmwRows = 12;
+inline int ws_regions(int maxT, int maxU1) { return (int)(((size_t)maxT * maxU1 + kRegionRows - 1) / kRegionRows); }
 inline size_t ws_partial_slots(int B, int maxT, int maxU1) {
   const size_t span_blocks = ((size_t)maxT * maxU1 + kMinSpanRows - 1) / kMinSpanRows;
-  return (size_t)B * (span_blocks > (size_t)maxT ? span_blocks : (size_t)maxT);
+  const size_t rmw_blocks = (size_t)ws_regions(maxT, maxU1) * ((kRegionRows + kMinRmwRows - 1) / kMinRmwRows + 1);
+  size_t per_utt = span_blocks > (size_t)maxT ? span_blocks : (size_t)maxT;
+  if (rmw_blocks > per_utt) per_utt = rmw_blocks;
+  return (size_t)B * per_utt;
 }
 
 // Lays the workspace out; returns total bytes.  base may be null (size query).
@@ -148,6 +170,12 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
   const size_t o_beta = take(sizeof(double) * plane);
   const int Dp = sweep_is_wide(maxU1) ? (D + kSweepBand - 1) / kSweepBand * kSweepBand + kSweepBand : 0;
   const size_t o_lp2 = Dp ? take(sizeof(float2) * (size_t)B * Dp * U1s) : 0;
+  const int row_words = (int)(((size_t)maxT * maxU1 + 63) / 64 * 2);
+  const size_t n_regions = (size_t)B * ws_regions(maxT, maxU1);
+  const size_t o_crec = joint ? 0 : take(sizeof(float4) * n_regions * kRegionStride);
+  const size_t o_rcount = joint ? 0 : take(sizeof(int) * n_regions);
+  const size_t o_items = joint ? 0 : take(sizeof(int) * n_regions * ((kRegionRows + kMinRmwRows - 1) / kMinRmwRows));
+  const size_t o_rowbits = joint ? 0 : take(sizeof(uint32_t) * (size_t)B * row_words);
   const size_t o_mf2 = joint ? take(sizeof(float) * (size_t)B * maxT) : 0;
   const size_t o_mg2 = joint ? take(sizeof(float) * (size_t)B * maxU1) : 0;
   const size_t o_fblank = joint ? take(sizeof(float) * (size_t)B * maxT) : 0;
@@ -177,6 +205,11 @@ size_t ws_layout(void* base, int B, int maxT, int maxU1, Ws* w, bool joint = fal
     w->beta = reinterpret_cast<double*>(p + o_beta);
     w->lp2 = Dp ? reinterpret_cast<float2*>(p + o_lp2) : nullptr;
     w->Dp = Dp;
+    w->crec = joint ? nullptr : reinterpret_cast<float4*>(p + o_crec);
+    w->rcount = joint ? nullptr : reinterpret_cast<int*>(p + o_rcount);
+    w->items = joint ? nullptr : reinterpret_cast<int*>(p + o_items);
+    w->rowbits = joint ? nullptr : reinterpret_cast<uint32_t*>(p + o_rowbits);
+    w->row_words = row_words;
     w->mf2 = joint ? reinterpret_cast<float*>(p + o_mf2) : nullptr;
     w->mg2 = joint ? reinterpret_cast<float*>(p + o_mg2) : nullptr;
     w->fblank = joint ? reinterpret_cast<float*>(p + o_fblank) : nullptr;

@@ -106,7 +106,7 @@ class _RNNTLossFn(torch.autograd.Function):
     are given the address of frame t_offset and the uncropped batch stride."""
 
     @staticmethod
-    def forward(ctx, acts_full, labels, il, ll, blank, inplace, check_inputs, t_offset):
+    def forward(ctx, acts_full, labels, il, ll, blank, inplace, check_inputs, t_offset, prune):
         B, T0, U1, V = acts_full.shape
         T = T0 - t_offset
         view = acts_full[:, t_offset:]
@@ -128,7 +128,7 @@ class _RNNTLossFn(torch.autograd.Function):
         # saved through autograd, so that an in-place edit of acts between forward and backward is detected
         ctx.save_for_backward(acts_full, labels, il, ll)
         ctx.ws = ws
-        ctx.blank, ctx.inplace, ctx.t_offset = blank, inplace, t_offset
+        ctx.blank, ctx.inplace, ctx.t_offset, ctx.prune = blank, inplace, t_offset, prune
         return costs
 
     @staticmethod
@@ -146,14 +146,14 @@ class _RNNTLossFn(torch.autograd.Function):
             if acts_full.is_contiguous():  # the library zero-fills the cropped frames itself
                 rc = _lib.lib().rnnt_mi355x_backward_cropped(_ptr(acts_full), _ptr(grad_full), _ptr(labels),
                                                              _ptr(il), _ptr(ll), B, T0, t_offset, U1, V, ctx.blank,
-                                                             _ptr(scale), _ptr(ctx.ws), _stream_ptr(dev))
+                                                             _ptr(scale), _ptr(ctx.ws), _stream_ptr(dev), ctx.prune)
             else:
                 view, gview = acts_full[:, t_offset:], grad_full[:, t_offset:]
                 xs = view.stride(0) if B > 1 else T * U1 * V
                 gs = gview.stride(0) if B > 1 else T * U1 * V
                 rc = _lib.lib().rnnt_mi355x_backward_strided(_ptr(view), xs, _ptr(gview), gs, _ptr(labels),
                                                              _ptr(il), _ptr(ll), B, T, U1, V, ctx.blank,
-                                                             _ptr(scale), _ptr(ctx.ws), _stream_ptr(dev))
+                                                             _ptr(scale), _ptr(ctx.ws), _stream_ptr(dev), ctx.prune)
                 if t_offset:
                     grad_full[:, :t_offset].zero_()  # the cropped frames take no part in the loss
             _lib.check(rc, "rnnt_mi355x_backward")
@@ -162,11 +162,11 @@ class _RNNTLossFn(torch.autograd.Function):
                 # its own backward (the op that produced it) gets an error instead of the gradient's bytes
                 torch.autograd.graph.increment_version(acts_full)
         ctx.ws = None
-        return grad_full, None, None, None, None, None, None, None
+        return grad_full, None, None, None, None, None, None, None, None
 
 
 def rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0, *, inplace=False, check_inputs=True,
-              t_offset=0):
+              t_offset=0, prune_log2=None):
     """Per-utterance transducer costs ``[B]``; same positional signature as the
     ``rnnt_loss`` the reference imports (reference rnnt/base/util.py:70-72,
     113-115), differentiable w.r.t. ``acts`` only.
@@ -186,7 +186,12 @@ def rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0, *, inpl
     check_inputs=True raises ValueError on malformed lengths/labels: lengths
     and labels given as host tensors are checked on the host; otherwise a 4-byte
     validation word is read back after the forward (one stream sync).
+    prune_log2: threshold of this call's backward (gradient elements that can be
+    bounded by grad_scale * 2^prune_log2 from the lattice state alone are written
+    as exact zeros without being computed); None = the process default (-28
+    unless changed with rnnt_mi355x_set_prune_log2), -inf = compute everything.
     """
+    prune = _lib.prune_arg(prune_log2)
     t_offset = int(t_offset)
     if not isinstance(acts, torch.Tensor) or acts.dim() != 4 or not 0 <= t_offset < acts.shape[1]:
         raise ValueError("acts must be a [B, T, U+1, V] tensor and 0 <= t_offset < T")
@@ -196,7 +201,8 @@ def rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0, *, inpl
         acts = acts.contiguous()  # a differentiable copy that nobody else reads: backward may overwrite it
         inplace = True
     # what the host has already validated needs no read-back (and no stream sync) after the forward
-    return _RNNTLossFn.apply(acts, labels, il, ll, blank, bool(inplace), bool(check_inputs) and not host_ok, t_offset)
+    return _RNNTLossFn.apply(acts, labels, il, ll, blank, bool(inplace), bool(check_inputs) and not host_ok, t_offset,
+                             prune)
 
 
 class _RNNTJointLossFn(torch.autograd.Function):
@@ -204,7 +210,7 @@ class _RNNTJointLossFn(torch.autograd.Function):
     [B,T,U+1,V]; frames t_offset.. of f take part (crop of util.py:101)."""
 
     @staticmethod
-    def forward(ctx, f_full, g, labels, il, ll, blank, check_inputs, t_offset):
+    def forward(ctx, f_full, g, labels, il, ll, blank, check_inputs, t_offset, prune):
         B, T0, V = f_full.shape
         U1 = g.shape[1]
         T = T0 - t_offset
@@ -221,7 +227,7 @@ class _RNNTJointLossFn(torch.autograd.Function):
                 _raise_on_flags(ws, dev)
         ctx.save_for_backward(f_full, g, labels, il, ll)
         ctx.ws = ws
-        ctx.blank, ctx.t_offset = blank, t_offset
+        ctx.blank, ctx.t_offset, ctx.prune = blank, t_offset, prune
         return costs
 
     @staticmethod
@@ -244,19 +250,23 @@ class _RNNTJointLossFn(torch.autograd.Function):
             dfs = dfview.stride(0) if B > 1 else T * V
             rc = _lib.lib().rnnt_mi355x_joint_backward(_ptr(fview), fs, _ptr(g), _ptr(labels), _ptr(il), _ptr(ll), B, T,
                                                        U1, V, ctx.blank, _ptr(scale), _ptr(dfview), dfs, _ptr(dg),
-                                                       _ptr(ws), _stream_ptr(dev))
+                                                       _ptr(ws), _stream_ptr(dev), ctx.prune)
             _lib.check(rc, "rnnt_mi355x_joint_backward")
             if t_offset:
                 df_full[:, :t_offset].zero_()
         ctx.ws = None
-        return df_full, dg, None, None, None, None, None, None
+        return df_full, dg, None, None, None, None, None, None, None
 
 
-def rnnt_joint_loss(f, g, labels, input_lengths, label_lengths, blank_label=0, *, check_inputs=True, t_offset=0):
+def rnnt_joint_loss(f, g, labels, input_lengths, label_lengths, blank_label=0, *, check_inputs=True, t_offset=0,
+                    prune_log2=None):
     """Costs ``[B]`` of the additive-joint transducer: equal to
     ``rnnt_loss(f[:, t_offset:, None, :] + g[:, None, :, :], ...)`` (the joint of
     reference rnnt/base/util.py:107-109) but the ``[B,T,U+1,V]`` tensor is never
-    formed; differentiable w.r.t. ``f`` [B,T0,V] and ``g`` [B,U+1,V]."""
+    formed; differentiable w.r.t. ``f`` [B,T0,V] and ``g`` [B,U+1,V].  prune_log2 as in
+    :func:`rnnt_loss` (here: lattice cells with occupancy below 2^prune_log2 are left
+    out of the gradient's contractions)."""
+    prune = _lib.prune_arg(prune_log2)
     t_offset = int(t_offset)
     if f.dim() != 3 or g.dim() != 3 or f.shape[0] != g.shape[0] or f.shape[2] != g.shape[2]:
         raise ValueError("f must be [B, T, V] and g [B, U+1, V]")
@@ -273,14 +283,15 @@ def rnnt_joint_loss(f, g, labels, input_lengths, label_lengths, blank_label=0, *
     labels, il, ll, blank, host_ok = _prepare_meta(B, T0 - t_offset, U1, V, f.device, labels, input_lengths,
                                                    label_lengths, blank_label)
     return _RNNTJointLossFn.apply(f.contiguous(), g.contiguous(), labels, il, ll, blank,
-                                  bool(check_inputs) and not host_ok, t_offset)
+                                  bool(check_inputs) and not host_ok, t_offset, prune)
 
 
 def rnnt_loss_grad_(acts, labels, input_lengths, label_lengths, blank_label=0, grad_scale=None, *, workspace=None,
-                    check_inputs=False):
+                    check_inputs=False, prune_log2=None):
     """Fused forward+backward without autograd: returns costs ``[B]`` and
     overwrites ``acts`` with d(sum_b grad_scale[b]*cost_b)/d(acts).  This is the
-    call bench.py times (one rnnt_mi355x_loss_grad)."""
+    call bench.py times (one rnnt_mi355x_loss_grad).  prune_log2 as in :func:`rnnt_loss`."""
+    prune = _lib.prune_arg(prune_log2)
     labels, il, ll, blank, host_ok = _prepare(acts, labels, input_lengths, label_lengths, blank_label)
     check_inputs = check_inputs and not host_ok
     if not acts.is_contiguous():
@@ -292,7 +303,7 @@ def rnnt_loss_grad_(acts, labels, input_lengths, label_lengths, blank_label=0, g
         costs = torch.empty(B, dtype=torch.float32, device=dev)
         gs = None if grad_scale is None else torch.as_tensor(grad_scale).to(device=dev, dtype=torch.float32).reshape(B).contiguous()
         rc = _lib.lib().rnnt_mi355x_loss_grad(_ptr(acts), _ptr(labels), _ptr(il), _ptr(ll), B, T, U1, V, blank,
-                                              _ptr(gs), _ptr(costs), _ptr(ws), _stream_ptr(dev))
+                                              _ptr(gs), _ptr(costs), _ptr(ws), _stream_ptr(dev), prune)
         _lib.check(rc, "rnnt_mi355x_loss_grad")
         if check_inputs:
             _raise_on_flags(ws, dev)

@@ -13,8 +13,9 @@ def _p(t):
 
 
 class HipRun:
-    def __init__(self, logits, labels, in_len, lab_len, blank, grad_scale=None, device="cuda:0"):
+    def __init__(self, logits, labels, in_len, lab_len, blank, grad_scale=None, device="cuda:0", prune_log2=None):
         self.dev = torch.device(device)
+        self.prune = _lib.prune_arg(prune_log2)  # None = the process default
         x = np.ascontiguousarray(logits, dtype=np.float32)
         self.B, self.T, self.U1, self.V = x.shape
         self.blank = int(blank)
@@ -41,11 +42,11 @@ class HipRun:
     def backward(self, out=None):
         g = self.x if out is None else out
         return _lib.lib().rnnt_mi355x_backward(_p(self.x), _p(g), _p(self.lab), _p(self.il), _p(self.ll), *self.meta(),
-                                               _p(self.gs), _p(self.ws), self.stream)
+                                               _p(self.gs), _p(self.ws), self.stream, self.prune)
 
     def loss_grad(self):
         return _lib.lib().rnnt_mi355x_loss_grad(_p(self.x), _p(self.lab), _p(self.il), _p(self.ll), *self.meta(),
-                                                _p(self.gs), _p(self.costs), _p(self.ws), self.stream)
+                                                _p(self.gs), _p(self.costs), _p(self.ws), self.stream, self.prune)
 
     def scalars(self):
         out = torch.empty(2, dtype=torch.float64, device=self.dev)

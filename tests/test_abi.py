@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_version_and_status_strings():
-    assert _lib.lib().rnnt_mi355x_version() == 102
+    assert _lib.lib().rnnt_mi355x_version() == 200
     assert _lib.status_string(0) == "ok"
     for rc in (1, 2, 3, 4, 99):
         assert _lib.status_string(rc)
@@ -55,8 +55,11 @@ def test_null_and_range_arguments_are_rejected_before_any_launch():
     assert L.rnnt_mi355x_forward(None, one, one, one, 1, 2, 2, 4, 0, one, one, None) == _lib.INVALID_VALUE
     assert L.rnnt_mi355x_forward(one, one, one, one, 1, 2, 2, 4, 4, one, one, None) == _lib.INVALID_VALUE
     assert L.rnnt_mi355x_forward(one, one, one, one, 1, 2, 2, 4, -1, one, one, None) == _lib.INVALID_VALUE
-    assert L.rnnt_mi355x_backward(one, None, one, one, one, 1, 2, 2, 4, 0, None, one, None) == _lib.INVALID_VALUE
-    assert L.rnnt_mi355x_loss_grad(one, one, one, one, 1, 2, 1100, 4, 0, None, one, one, None) == _lib.UNSUPPORTED_SIZE
+    nan = float("nan")
+    assert L.rnnt_mi355x_backward(one, None, one, one, one, 1, 2, 2, 4, 0, None, one, None, nan) == _lib.INVALID_VALUE
+    assert L.rnnt_mi355x_loss_grad(one, one, one, one, 1, 2, 1100, 4, 0, None, one, one, None, nan) == _lib.UNSUPPORTED_SIZE
+    # a per-call threshold above -16 is refused like one set process-wide
+    assert L.rnnt_mi355x_backward(one, one, one, one, one, 1, 2, 2, 4, 0, None, one, None, -8.0) == _lib.INVALID_VALUE
     assert L.rnnt_mi355x_reduce_scalars(None, 1, one, one, None) == _lib.INVALID_VALUE
 
 
@@ -73,8 +76,9 @@ def test_prune_threshold_setting_and_static_entry_point_validation():
     # the entry point with the built-in workspace rejects what does not fit it, before touching a GPU
     assert _lib.workspace_bytes(8, 150, 41) < _lib.STATIC_WORKSPACE_BYTES < _lib.workspace_bytes(64, 400, 101)
     f = L.rnnt_mi355x_loss_grad_static
-    assert f(one, one, one, one, 64, 400, 101, 1024, 0, None, one, None, None, None) == _lib.UNSUPPORTED_SIZE
-    assert f(one, one, one, one, 1, 2, 2, 4, 4, None, one, None, None, None) == _lib.INVALID_VALUE   # blank outside [0,V)
+    nan = float("nan")
+    assert f(one, one, one, one, 64, 400, 101, 1024, 0, None, one, None, None, None, nan) == _lib.UNSUPPORTED_SIZE
+    assert f(one, one, one, one, 1, 2, 2, 4, 4, None, one, None, None, None, nan) == _lib.INVALID_VALUE   # blank outside [0,V)
     assert L.rnnt_mi355x_read_stats(None, None, None, None) == _lib.INVALID_VALUE
 
 
@@ -98,7 +102,8 @@ def test_new_entry_points_validate_without_a_gpu():
     # crop as an argument
     assert L.rnnt_mi355x_forward_cropped(one, one, one, one, 1, 4, 4, 2, 4, 0, one, one, None) == _lib.INVALID_VALUE  # nothing left
     assert L.rnnt_mi355x_forward_cropped(one, one, one, one, 1, 4, -1, 2, 4, 0, one, one, None) == _lib.INVALID_VALUE
-    assert L.rnnt_mi355x_backward_cropped(one, None, one, one, one, 1, 4, 2, 2, 4, 0, None, one, None) == _lib.INVALID_VALUE
+    assert L.rnnt_mi355x_backward_cropped(one, None, one, one, one, 1, 4, 2, 2, 4, 0, None, one, None,
+                                          float("nan")) == _lib.INVALID_VALUE
     # FC-joint first layer and Dense layers
     assert _lib.fc_joint_workspace_bytes(2, 17, 5, 100) == 4 * 2 * 3 * 5 * 100   # ceil(17 / 8) frame chunks
     assert L.rnnt_mi355x_fc_joint_workspace_bytes(1, 1, 1, 1537, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE

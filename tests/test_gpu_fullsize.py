@@ -8,7 +8,7 @@ Properties used:
   * identical utterances give bit-identical costs and gradients wherever they
     sit in the batch (also beyond the 2^31-element mark of the logits tensor);
   * cells beyond an utterance's lengths are exact zeros;
-  * rows the gradient kernel prunes are rows whose exact gradient is negligible.
+  * whatever the gradient kernel writes as zero without computing it is negligible in the exact gradient.
 """
 import numpy as np
 import pytest
@@ -34,11 +34,12 @@ def _gpu_batch(B, T, U, V, blank, seed, il=None, ll=None):
     return x, lab, il, ll
 
 
-def _run(x, lab, il, ll, blank, gs=None):
+def _run(x, lab, il, ll, blank, gs=None, prune_log2=None, stream=None):
     run = HipRun.__new__(HipRun)
     import ctypes
     from rnnt_amd import _lib
     run.dev = x.device
+    run.prune = _lib.prune_arg(prune_log2)
     run.B, run.T, run.U1, run.V = x.shape
     run.blank = blank
     run.x, run.lab = x, lab
@@ -47,8 +48,10 @@ def _run(x, lab, il, ll, blank, gs=None):
     run.gs = gs
     run.ws = torch.empty(_lib.workspace_bytes(run.B, run.T, run.U1), dtype=torch.uint8, device=x.device)
     run.costs = torch.full((run.B,), float("nan"), dtype=torch.float32, device=x.device)
-    run.stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    run.stream = ctypes.c_void_p((stream or torch.cuda.current_stream(x.device)).cuda_stream)
     assert run.loss_grad() == 0
+    if stream is not None:  # the caller waits for its streams itself
+        return run
     torch.cuda.synchronize()
     assert run.flags() == (0, 0)
     return run
@@ -129,10 +132,14 @@ def test_config5_ragged_padded_cells_and_subset_parity():
     _subset_parity(before, sub, lab[picks], il[picks], ll[picks], blank, [0, 1, 2])
 
 
-def test_pruned_rows_are_truly_negligible():
-    """Rows the gradient kernel zero-fills without reading (occupancy below
-    2^-28) must be ones whose exact gradient is below that everywhere."""
-    B, T, U, V, blank = 1, 300, 80, 64, 63
+@pytest.mark.parametrize("V,blank", [(64, 63), (62, 39), (1024, 7), (300, 299)])
+def test_pruned_rows_are_truly_negligible(V, blank):
+    """What the gradient kernels write as exact zero without reading the logits
+    again (whole rows whose occupancy is below 2^-28, and all but the blank's
+    and the label's entry of rows whose largest probability times the
+    occupancy is) must be below 2^-28 in the exact gradient, element by
+    element."""
+    B, T, U = 1, 300, 80
     x, lab, il, ll = _gpu_batch(B, T, U, V, blank, seed=5)
     xh = x.cpu().numpy()
     run = _run(x, lab, il, ll, blank)
@@ -140,15 +147,21 @@ def test_pruned_rows_are_truly_negligible():
     g = run.x.cpu().numpy()
     zero_rows = ~g.any(-1)
     assert zero_rows.mean() > 0.2                       # the prune does fire at this size
-    assert np.abs(go[zero_rows]).max() < 2.0 ** -28
+    assert np.abs(go[g == 0]).max() < 2.0 ** -28
     assert np.abs(g - go).max() < 2e-5
+    if V % 4 == 0 or V > 128:  # the kernels that also take sparse rows (not the row-per-lane ones of V = 62)
+        nnz = np.count_nonzero(g, -1)
+        sparse = (nnz >= 1) & (nnz <= 2)
+        assert sparse.sum() > 50, sparse.sum()
+        # their two entries are the exact ones
+        assert np.abs((g - go)[sparse]).max() < 2.0 ** -28
 
 
 @pytest.mark.parametrize("V,blank", [(64, 63), (256, 0)])
 def test_prune_threshold_is_a_runtime_setting_and_is_counted(V, blank):
-    """rnnt_mi355x_set_prune_log2 moves the occupancy threshold of the gradient pass (both the row-per-lane and the
-    lanes-per-row kernels), rnnt_mi355x_read_stats counts what it pruned; every pruned row's exact gradient is
-    bounded by the threshold, and with pruning off the result is the dense one."""
+    """The prune_log2 argument of a call moves the threshold of its gradient pass, rnnt_mi355x_read_stats counts the
+    rows that were not read a second time; every element written as zero is bounded by the threshold in the exact
+    gradient, and with pruning off the result is the dense one."""
     import ctypes
     from rnnt_amd import _lib
     from tests.hip_runner import _p
@@ -160,27 +173,49 @@ def test_prune_threshold_is_a_runtime_setting_and_is_counted(V, blank):
     cells_expected = int((il.astype(np.int64) * (ll.astype(np.int64) + 1)).sum())
     L = _lib.lib()
     fracs = {}
-    try:
-        for thr in (float("-inf"), -40.0, -24.0, -16.0):
-            assert L.rnnt_mi355x_set_prune_log2(thr) == 0
-            run = _run(x.clone(), lab, il, ll, blank)
-            cells, pruned = _lib.read_stats(_p(run.ws), run.stream)
-            assert cells == cells_expected
-            g = run.x.cpu().numpy()
-            lattice = np.zeros(g.shape[:3], bool)
-            for b in range(B):
-                lattice[b, :il[b], :ll[b] + 1] = True
-            zero_rows = ~g.any(-1) & lattice
-            if thr > float("-inf"):  # (with pruning off, far-off rows still underflow to zeros)
-                assert zero_rows.sum() == pruned
-            fracs[thr] = pruned / cells
-            if pruned:
-                assert np.abs(go[zero_rows]).max() <= 2.0 ** thr * 1.001
-            assert np.abs(g - go).max() < 2e-5 + 2.0 ** thr
-    finally:
-        assert L.rnnt_mi355x_set_prune_log2(_lib.DEFAULT_PRUNE_LOG2) == 0
+    for thr in (float("-inf"), -40.0, -24.0, -16.0):
+        run = _run(x.clone(), lab, il, ll, blank, prune_log2=thr)
+        cells, pruned = _lib.read_stats(_p(run.ws), run.stream)
+        assert cells == cells_expected
+        g = run.x.cpu().numpy()
+        lattice = np.zeros(g.shape[:3], bool)
+        for b in range(B):
+            lattice[b, :il[b], :ll[b] + 1] = True
+        unread_rows = (np.count_nonzero(g, -1) <= 2) & lattice   # pruned rows, and sparse ones (two exact entries)
+        if thr > float("-inf"):  # (with pruning off, far-off rows still underflow to zeros)
+            assert unread_rows.sum() == pruned
+        fracs[thr] = pruned / cells
+        if pruned:
+            assert np.abs(go[(g == 0) & lattice[..., None]]).max() <= 2.0 ** thr * 1.001
+        assert np.abs(g - go).max() < 2e-5 + 2.0 ** thr
+    assert L.rnnt_mi355x_get_prune_log2() == _lib.DEFAULT_PRUNE_LOG2  # per-call thresholds leave the default alone
     assert fracs[float("-inf")] == 0.0
     assert fracs[-40.0] > 0.1 and fracs[-16.0] > fracs[-24.0] > fracs[-40.0]
+
+
+def test_prune_threshold_is_per_call_also_on_two_streams():
+    """Two calls enqueued back to back on two streams with different thresholds (and a third process default in
+    force) each get their own result: bit-equal to the same call made alone."""
+    from rnnt_amd import _lib
+    B, T, U, V, blank = 2, 200, 50, 256, 255
+    x, lab, il, ll = _gpu_batch(B, T, U, V, blank, seed=23)
+    alone = {thr: _run(x.clone(), lab, il, ll, blank, prune_log2=thr).x.clone() for thr in (float("-inf"), -16.0)}
+    assert not torch.equal(alone[float("-inf")], alone[-16.0])
+    dev = x.device
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    xa, xb = x.clone(), x.clone()
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    try:
+        assert L.rnnt_mi355x_set_prune_log2(-20.0) == 0
+        ra = _run(xa, lab, il, ll, blank, prune_log2=float("-inf"), stream=s1)
+        rb = _run(xb, lab, il, ll, blank, prune_log2=-16.0, stream=s2)
+        rc = _run(x.clone(), lab, il, ll, blank)  # no argument: the process default, -20
+        torch.cuda.synchronize()
+    finally:
+        assert L.rnnt_mi355x_set_prune_log2(_lib.DEFAULT_PRUNE_LOG2) == 0
+    assert torch.equal(ra.x, alone[float("-inf")]) and torch.equal(rb.x, alone[-16.0])
+    assert torch.equal(rc.x, _run(x.clone(), lab, il, ll, blank, prune_log2=-20.0).x)
 
 
 @pytest.mark.parametrize("B,T,U,V,blank", [(32, 500, 100, 62, 39), (16, 400, 100, 1024, 1023)])

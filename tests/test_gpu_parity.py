@@ -307,14 +307,14 @@ def test_batch_strided_entry_points(V, blank):
     assert rc == 0
     out = torch.full((B, T, U + 1, V), float("nan"), device=dev)
     rc = L.rnnt_mi355x_backward_strided(p(view), stride, p(out), T * (U + 1) * V, p(run.lab), p(run.il), p(run.ll),
-                                        B, T, U + 1, V, blank, p(run.gs), p(run.ws), run.stream)
+                                        B, T, U + 1, V, blank, p(run.gs), p(run.ws), run.stream, run.prune)
     assert rc == 0
     torch.cuda.synchronize()
     np.testing.assert_allclose(run.costs.cpu().numpy(), co, rtol=COST_RTOL)
     assert np.abs(out.cpu().numpy() - go).max() < GRAD_ATOL_TIGHT
     assert torch.equal(t_full.cpu(), torch.from_numpy(full))       # logits untouched so far
     rc = L.rnnt_mi355x_backward_strided(p(view), stride, p(view), stride, p(run.lab), p(run.il), p(run.ll),
-                                        B, T, U + 1, V, blank, p(run.gs), p(run.ws), run.stream)
+                                        B, T, U + 1, V, blank, p(run.gs), p(run.ws), run.stream, run.prune)
     assert rc == 0
     torch.cuda.synchronize()
     got = t_full.cpu().numpy()

@@ -306,7 +306,7 @@ def test_random_malformed_inputs_to_the_fused_joint(seed):
     df, dg = torch.full_like(tf_, 7.0), torch.full_like(tg, 7.0)
     assert L.rnnt_mi355x_joint_forward(p(tf_), 0, p(tg), p(tl), p(til), p(tll), B, T, U + 1, V, blank, p(costs), p(ws), None) == 0
     assert L.rnnt_mi355x_joint_backward(p(tf_), 0, p(tg), p(tl), p(til), p(tll), B, T, U + 1, V, blank, p(tgs), p(df), 0,
-                                        p(dg), p(ws), None) == 0
+                                        p(dg), p(ws), None, float("nan")) == 0
     flags = ctypes.c_int32(0)
     rc = L.rnnt_mi355x_read_status(p(ws), ctypes.byref(flags), None)
     assert flags.value == want_flags and rc == (4 if want_flags else 0), (flags.value, want_flags)

@@ -361,7 +361,8 @@ def test_entry_points_can_be_captured_in_a_hip_graph():
     def step(stream):
         sp = ctypes.c_void_p(stream.cuda_stream)
         buf.copy_(master)
-        assert L.rnnt_mi355x_loss_grad(p(buf), p(t_lab), p(t_il), p(t_ll), 4, 30, 13, 62, 39, p(gs), p(costs), p(ws), sp) == 0
+        assert L.rnnt_mi355x_loss_grad(p(buf), p(t_lab), p(t_il), p(t_ll), 4, 30, 13, 62, 39, p(gs), p(costs), p(ws), sp,
+                                       float("nan")) == 0
         assert L.rnnt_mi355x_reduce_scalars(p(costs), 4, p(ws), p(scal), sp) == 0
 
     side = torch.cuda.Stream(dev)

@@ -32,7 +32,7 @@ def _static_call(x, lab, il, ll, blank, gs):
     torch.cuda.synchronize()
     before = (torch.cuda.memory_allocated(dev), torch.cuda.mem_get_info(dev)[0])
     rc = _lib.lib().rnnt_mi355x_loss_grad_static(_p(xs), _p(labd), _p(ild), _p(lld), B, T, U1, V, blank, _p(gsd),
-                                                 _p(costs), _p(scal), _p(flags), stream)
+                                                 _p(costs), _p(scal), _p(flags), stream, float("nan"))
     assert rc == 0, _lib.status_string(rc)
     torch.cuda.synchronize()
     # nothing was allocated, neither through torch nor behind its back (free device memory is unchanged)
@@ -58,7 +58,7 @@ def test_static_workspace_entry_point_matches_loss_grad_on_two_calls_in_a_row():
 
 def test_static_workspace_entry_point_rejects_what_does_not_fit():
     one = ctypes.c_void_p(256)  # never dereferenced: the size check comes first
-    rc = _lib.lib().rnnt_mi355x_loss_grad_static(one, one, one, one, 64, 400, 101, 1024, 0, None, one, None, None, None)
+    rc = _lib.lib().rnnt_mi355x_loss_grad_static(one, one, one, one, 64, 400, 101, 1024, 0, None, one, None, None, None, float("nan"))
     assert rc == _lib.UNSUPPORTED_SIZE
 
 
