@@ -72,6 +72,25 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify_rows(const int32_t*
   const int maxU1 = gm.maxU1;
   int T, U;
   utt_dims(in_len, lab_len, b, gm.maxT, maxU1, T, U);
+  if (reg * kRegionRows >= T * maxU1) {  // (block-uniform) a region of padding: nothing to load, nothing but zeros
+    const int row = reg * kRegionRows + 4 * (int)threadIdx.x;  // 4 * 512 = the region's rows, 32 per word
+    if ((threadIdx.x & 7) == 0 && (row >> 5) < w.row_words) w.rowbits[(size_t)b * w.row_words + (row >> 5)] = 0u;
+    for (int j = threadIdx.x; j <= gm.spb; j += kClassifyBlock) w.partial[(size_t)regid * (gm.spb + 1) + j] = 0.f;
+    if (threadIdx.x == 0) {
+      const unsigned long long old = atomicAdd(&w.hdr->items_ctr, 1ull << 32);
+      if ((int)(old >> 32) == (int)(gridDim.x * gridDim.y) - 1) {
+        w.hdr->n_items_ready = (int)(old & 0xffffffffull);
+        atomicExch(&w.hdr->items_ctr, 0ull);
+      }
+      w.rcount[regid] = 0;
+      w.pcount[regid] = make_uint2(0u, 0u);
+      if (regid == 0) {  // (not reached: region 0 of utterance 0 holds cells unless its lengths are invalid)
+        w.hdr->n_count = (int)(gridDim.x * gridDim.y);
+        w.hdr->n_partial = (int)(gridDim.x * gridDim.y) * (gm.spb + 1);
+      }
+    }
+    return;
+  }
   const int U1s = w.U1s;
   const double ll2 = w.ll[b];
   // Everything the region's cells need is requested at once, before the lengths are looked at (addresses clamped
@@ -189,11 +208,16 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify_rows(const int32_t*
   if ((int)threadIdx.x < n_items) w.items[first_item + threadIdx.x] = (regid << 8) | (int)threadIdx.x;
 }
 
-// One wavefront per KiB of an utterance's gradient; row_kib = KiB per row (>= 1).  grid (ceil(KiB per utterance / 4), B).
-__global__ __launch_bounds__(256) void k_fill_rows(float* __restrict__ grad, size_t gstride, int kib_utt, int row_kib,
+// One wavefront per KiB of an utterance's gradient; row_kib = KiB per row (>= 1).
+// grid (ceil(KiB per utterance / kFillWaves), B).
+#ifndef RNNT_FILL_WAVES
+#define RNNT_FILL_WAVES 4
+#endif
+constexpr int kFillWaves = RNNT_FILL_WAVES;
+__global__ __launch_bounds__(kFillWaves * 64) void k_fill_rows(float* __restrict__ grad, size_t gstride, int kib_utt, int row_kib,
                                                    const uint32_t* __restrict__ rowbits, int row_words) {
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int kib = (int)blockIdx.x * 4 + wv;  // wave-uniform
+  const int kib = (int)blockIdx.x * kFillWaves + wv;  // wave-uniform
   if (kib >= kib_utt) return;
   const int b = blockIdx.y;
   const int row = row_kib == 1 ? kib : kib / row_kib;

@@ -466,11 +466,30 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
       const int row_kib = c.V / 256;
       const long long kib_utt = (long long)sg.rows_utt * row_kib;  // < 2^31: rows < 2^31 / B and V <= 4096
       auto fill = [&]() {
-        k_fill_rows<<<dim3((unsigned)((kib_utt + 3) / 4), (unsigned)c.B), 256, 0, st>>>(c.grad, c.gstride, (int)kib_utt, row_kib,
-                                                                                     c.w.rowbits, c.w.row_words);
+        k_fill_rows<<<dim3((unsigned)((kib_utt + kFillWaves - 1) / kFillWaves), (unsigned)c.B), kFillWaves * 64, 0, st>>>(
+            c.grad, c.gstride, (int)kib_utt, row_kib, c.w.rowbits, c.w.row_words);
         k_patch_sparse<<<per_region, 256, 0, st>>>(c.grad, c.grad_scale, sp, c.w);
       };
-#ifdef RNNT_SPLIT_FILL_FIRST
+#if defined(RNNT_SPLIT_OVERLAP)  // experiment: the zero-fill on a second stream underneath the read-modify-write kernel
+      static hipStream_t side = nullptr;
+      static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+      if (!side) {
+        (void)hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+      }
+      (void)hipEventRecord(ev_fork, st);
+      (void)hipStreamWaitEvent(side, ev_fork, 0);
+      {
+        hipStream_t main_st = st;
+        st = side;
+        fill();
+        st = main_st;
+      }
+      (void)hipEventRecord(ev_join, side);
+      rmw();
+      (void)hipStreamWaitEvent(st, ev_join, 0);
+#elif defined(RNNT_SPLIT_FILL_FIRST)
       fill();
       rmw();
 #else
