@@ -25,6 +25,7 @@ __global__ __launch_bounds__(64) void k_init(Ws w, int n_partial) {
     w.hdr->n_count = n_partial;
     w.hdr->n_items_ready = 0;
     w.hdr->items_ctr = 0ull;
+    w.hdr->rmw_next = 0u;
     w.hdr->partial_off = w.partial_off;
     w.hdr->count_off = w.count_off;
     w.hdr->n_cells = 0;

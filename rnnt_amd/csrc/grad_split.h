@@ -43,9 +43,19 @@ namespace {
 #ifndef RNNT_RMW_PACE  // stores (of 1 KiB per wavefront) between two drains of k_grad_rmw's write phase; 0 = none
 #define RNNT_RMW_PACE RNNT_SPAN_PACE
 #endif
-constexpr int kClassifyBlock = 512;
-constexpr int kClassifyIters = kRegionRows / kClassifyBlock;
-static_assert(kRegionRows % kClassifyBlock == 0 && kRegionRows <= 65536, "a row's number inside its region is packed into 16 bits");
+#ifndef RNNT_RMW_WAVES  // wavefronts per block of k_grad_rmw
+#define RNNT_RMW_WAVES RNNT_SPAN_WAVES
+#endif
+#ifndef RNNT_RMW_PER_CU  // its resident blocks per compute unit (their registers allow 12 wavefronts)
+#define RNNT_RMW_PER_CU (12 / RNNT_RMW_WAVES)
+#endif
+constexpr int kRmwWaves = RNNT_RMW_WAVES;
+constexpr int kClassifyIters = 4;  // rows per thread of k_classify_rows
+constexpr int kClassifyBlock = kRegionRows / kClassifyIters;
+static_assert(kRegionRows % (64 * kClassifyIters) == 0 && kClassifyBlock <= 1024 && kRegionRows <= 65536,
+              "whole wavefronts; a row's number inside its region is packed into 16 bits");
+constexpr int kItemBits = 10;  // a work item's code: (region id << kItemBits) | its number inside the region
+constexpr int kItemMask = (1 << kItemBits) - 1;
 
 struct SplitGeom {
   int maxT, maxU1, V, blank;
@@ -73,13 +83,15 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify_rows(const int32_t*
   int T, U;
   utt_dims(in_len, lab_len, b, gm.maxT, maxU1, T, U);
   if (reg * kRegionRows >= T * maxU1) {  // (block-uniform) a region of padding: nothing to load, nothing but zeros
-    const int row = reg * kRegionRows + 4 * (int)threadIdx.x;  // 4 * 512 = the region's rows, 32 per word
+    const int row = reg * kRegionRows + kClassifyIters * (int)threadIdx.x;  // the region's rows, 32 per word
+    static_assert(kClassifyIters == 4, "a thread in eight clears a word of 32 row bits");
     if ((threadIdx.x & 7) == 0 && (row >> 5) < w.row_words) w.rowbits[(size_t)b * w.row_words + (row >> 5)] = 0u;
     for (int j = threadIdx.x; j <= gm.spb; j += kClassifyBlock) w.partial[(size_t)regid * (gm.spb + 1) + j] = 0.f;
     if (threadIdx.x == 0) {
       const unsigned long long old = atomicAdd(&w.hdr->items_ctr, 1ull << 32);
       if ((int)(old >> 32) == (int)(gridDim.x * gridDim.y) - 1) {
         w.hdr->n_items_ready = (int)(old & 0xffffffffull);
+        w.hdr->rmw_next = 0u;
         atomicExch(&w.hdr->items_ctr, 0ull);
       }
       w.rcount[regid] = 0;
@@ -156,7 +168,21 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify_rows(const int32_t*
   __syncthreads();
   // Compaction in row order (entries of (iteration, wavefront) pairs before this one, then lanes below this one):
   // the full rows from the front of the region's stretch of crec, the sparse ones from its end backwards.
+  // A region's last work item is seldom whole.  Its entries are spread evenly over the wavefronts of k_grad_rmw
+  // (wavefront w of that kernel takes entries [w * ng, (w + 1) * ng) of an item: each gets a run of `per_wave`
+  // consecutive ones, the rest of its slots stand for nothing), so that the item takes as long as its fullest
+  // wavefront needs, not as long as a whole item.
   float4* out = w.crec + (size_t)regid * kRegionStride;
+  int total = 0;
+#pragma unroll
+  for (int it = 0; it < kClassifyIters; ++it)
+#pragma unroll
+    for (int i = 0; i < NW; ++i) total += wcnt[0][it][i];
+  const int n_items = (total + gm.rb - 1) / gm.rb;
+  const int last0 = (n_items - 1) * gm.rb;         // first entry of the last item
+  const int n_last = total - last0;                // its entries (n_items > 0)
+  const int ng = gm.rb / kRmwWaves;
+  const int per_wave = (n_last + kRmwWaves - 1) / kRmwWaves;
   int base = 0, sbase = 0;
 #pragma unroll
   for (int it = 0; it < kClassifyIters; ++it) {
@@ -172,14 +198,22 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify_rows(const int32_t*
     const int local_row = it * kClassifyBlock + (int)threadIdx.x;
     const float4 e = make_float4(cf[it].x, cf[it].y, cf[it].z, pack_row_label(local_row, __float_as_int(cf[it].w)));
     const unsigned long long below = (1ull << lane) - 1ull;
-    if ((mask[it] >> lane) & 1ull) out[mine + __popcll(mask[it] & below)] = e;
+    if ((mask[it] >> lane) & 1ull) {
+      int pos = mine + __popcll(mask[it] & below);
+      if (pos >= last0) {
+        const int j = pos - last0;
+        pos = last0 + (j / per_wave) * ng + (j % per_wave);
+      }
+      out[pos] = e;
+    }
     if ((smask[it] >> lane) & 1ull) out[kRegionStride - 1 - (smine + __popcll(smask[it] & below))] = e;
   }
-  // `base` is now the region's number of entries: pad them to whole work items with entries that stand for nothing,
-  // clear the region's slots of the per-item sums, and append the region's items to the list
-  const int n_items = (base + gm.rb - 1) / gm.rb;
-  if ((int)threadIdx.x < n_items * gm.rb - base)
-    out[base + threadIdx.x] = make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
+  // the last item's slots that no entry went to, and the region's slots of the per-item sums
+  if (n_items > 0 && (int)threadIdx.x < gm.rb) {
+    const int wslot = (int)threadIdx.x / ng, g = (int)threadIdx.x - wslot * ng;
+    if (g >= per_wave || wslot * per_wave + g >= n_last)
+      out[last0 + threadIdx.x] = make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
+  }
   for (int j = threadIdx.x; j < gm.spb; j += kClassifyBlock) w.partial[(size_t)regid * (gm.spb + 1) + j] = 0.f;
   // One atomic per block hands out the items' places and counts the blocks: the block that finds every other block
   // counted knows the final number of items, stores it for k_grad_rmw and leaves the counter at zero for the next
@@ -190,6 +224,7 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify_rows(const int32_t*
     first_item = (int)(old & 0xffffffffull);
     if ((int)(old >> 32) == (int)(gridDim.x * gridDim.y) - 1) {
       w.hdr->n_items_ready = first_item + n_items;
+      w.hdr->rmw_next = 0u;
       atomicExch(&w.hdr->items_ctr, 0ull);
     }
     w.rcount[regid] = sbase;  // what k_patch_sparse has to do in this region
@@ -205,7 +240,7 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify_rows(const int32_t*
     }
   }
   __syncthreads();
-  if ((int)threadIdx.x < n_items) w.items[first_item + threadIdx.x] = (regid << 8) | (int)threadIdx.x;
+  if ((int)threadIdx.x < n_items) w.items[first_item + threadIdx.x] = (regid << kItemBits) | (int)threadIdx.x;
 }
 
 // One wavefront per KiB of an utterance's gradient; row_kib = KiB per row (>= 1).
@@ -251,21 +286,22 @@ __global__ __launch_bounds__(256) void k_patch_sparse(float* __restrict__ grad, 
 // entries per work item and items per region of k_grad_rmw<NC, NG> (one row per wavefront instruction: rows of >= 1 KiB)
 template <int NG>
 struct RmwShape {
-  static constexpr int RB = kSpanWaves * NG;
+  static constexpr int RB = kRmwWaves * NG;
   static_assert(RB <= kRegionStride - kRegionRows, "a region's entries are padded to a whole work item inside its stretch");
   static constexpr int SPB = (kRegionRows + RB - 1) / RB;
-  static_assert(SPB <= 256, "an item's number inside its region is packed into 8 bits");
+  static_assert(SPB <= kItemMask + 1 && SPB <= kClassifyBlock, "an item's number inside its region is packed into kItemBits bits; a thread of k_classify_rows per item");
 };
 
 #ifdef RNNT_RMW_TIMING  // experiment builds: cycles spent per phase, summed over blocks (thread 0's clock)
 __device__ unsigned long long g_rmw_dbg[8];
+__device__ unsigned long long g_rmw_span[2][1024];  // wall clock (100 MHz) at which a block started / ended
 #define RMW_T(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_rmw_dbg[i], now_ - t_last_); t_last_ = now_; } } while (0)
 #else
 #define RMW_T(i) do { } while (0)
 #endif
 
 template <int NC, int NG>
-__global__ __launch_bounds__(kSpanWaves * 64) __attribute__((amdgpu_waves_per_eu(RNNT_SPAN_OCC))) void k_grad_rmw(
+__global__ __launch_bounds__(kRmwWaves * 64) __attribute__((amdgpu_waves_per_eu(RNNT_SPAN_OCC))) void k_grad_rmw(
     const float* x, float* grad, const float* __restrict__ grad_scale, SplitGeom gm, Ws w) {
   constexpr int RB = RmwShape<NG>::RB, SPB = RmwShape<NG>::SPB;
   static_assert(RB >= kMinRmwRows, "the workspace holds one partial-sum slot per kMinRmwRows entries of a region");
@@ -274,20 +310,32 @@ __global__ __launch_bounds__(kSpanWaves * 64) __attribute__((amdgpu_waves_per_eu
   const int nchunk = V >> 2;
 #ifdef RNNT_RMW_TIMING
   unsigned long long t_last_ = __builtin_readcyclecounter();
+  if (threadIdx.x == 0 && blockIdx.x < 1024) { g_rmw_span[0][blockIdx.x] = wall_clock64(); g_rmw_span[1][blockIdx.x] = wall_clock64(); }
 #endif
   const int n_items = w.hdr->n_items_ready;
-  const int stride = (int)gridDim.x;
-  int item = (int)blockIdx.x;
-  if (item >= n_items) return;  // (block-uniform)
+  if ((int)blockIdx.x >= n_items) return;  // (block-uniform)
   __shared__ float4 coef_buf[2][RB];
-  __shared__ float red[kSpanWaves];
-  // the item after this one is looked up, and its entries requested, while this one is worked on: they travel during
-  // the read phase and are parked in the other half of coef_buf right after it
-  int code = w.items[item];
-  int code_next = item + stride < n_items ? w.items[item + stride] : -1;
+  __shared__ float red[kRmwWaves];
+  __shared__ int code_s[2];
+  // Work items are handed out by a counter as blocks come free.  Blocks do not run at one pace, and fewer of them
+  // may be resident than the grid holds (measured: half of a grid of two per compute unit started when the other
+  // half had finished, and blocks took 0.4 to 0.9 ms for equal shares): with a fixed share per block the kernel
+  // ended when the slowest block had worked its share off.  Thread 0 draws a number two items ahead and looks its
+  // code up one item ahead; every thread requests the next item's entries while this item is worked on: they travel
+  // during the read phase and are parked in the other half of coef_buf right after it.
+  auto code_of = [&](unsigned int idx) { return idx < (unsigned int)n_items ? w.items[idx] : -1; };
+  if (threadIdx.x == 0) {
+    const unsigned int first = atomicAdd(&w.hdr->rmw_next, 2u);
+    code_s[0] = code_of(first);
+    code_s[1] = code_of(first + 1u);
+  }
+  __syncthreads();
+  int code = code_s[0];
+  int code_next = code_s[1];
+  if (code < 0) return;  // (block-uniform) a block that starts when nothing is left
   auto entries_of = [&](int c) {
     float4 e = make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
-    if (threadIdx.x < RB) e = w.crec[(size_t)(c >> 8) * kRegionStride + (c & 255) * RB + threadIdx.x];
+    if (threadIdx.x < RB) e = w.crec[(size_t)(c >> kItemBits) * kRegionStride + (c & kItemMask) * RB + threadIdx.x];
     return e;
   };
   {
@@ -298,13 +346,13 @@ __global__ __launch_bounds__(kSpanWaves * 64) __attribute__((amdgpu_waves_per_eu
   RMW_T(0);  // first item's entries have arrived
   for (int cur = 0;; cur ^= 1) {
     const float4* coef_s = coef_buf[cur];
-    const int regid = code >> 8, k = code & 255;
+    const int regid = code >> kItemBits, k = code & kItemMask;
     const int b = regid / gm.regions_utt;
     const int reg = regid - b * gm.regions_utt;
     const float sc = grad_scale ? grad_scale[b] : 1.f;
-    item += stride;
     code = code_next;
-    code_next = item + stride < n_items ? w.items[item + stride] : -1;
+    unsigned int ticket = 0u;
+    if (threadIdx.x == 0 && code >= 0) ticket = atomicAdd(&w.hdr->rmw_next, 1u);  // (requested with the row loads)
     float4 mine = make_float4(-INFINITY, 0.f, 0.f, __int_as_float(-1));
     if (code >= 0) mine = entries_of(code);
     const size_t reg_off = (size_t)reg * kRegionRows * V;
@@ -317,7 +365,11 @@ __global__ __launch_bounds__(kSpanWaves * 64) __attribute__((amdgpu_waves_per_eu
     for (int g = 0; g < NG; ++g) {
       const float4 cf = coef_s[wv * NG + g];
       const bool active = cf.x > -INFINITY;
+#ifdef RNNT_RMW_FAKE_CONTIG  // timing experiment only (wrong results): an item's rows as one contiguous run
+      const float* rp = xreg + (size_t)((k * RB + wv * NG + g) % kRegionRows) * V;
+#else
       const float* rp = xreg + (size_t)(__float_as_int(cf.w) >> 16) * V;  // (not dereferenced for entries that stand for nothing)
+#endif
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
@@ -333,6 +385,8 @@ __global__ __launch_bounds__(kSpanWaves * 64) __attribute__((amdgpu_waves_per_eu
     __syncthreads();  // the block's rows turn from reading to writing together
     RMW_T(2);  // barrier passed (not: loads arrived)
     if (threadIdx.x < RB) coef_buf[cur ^ 1][threadIdx.x] = mine;
+    int code_after = -1;  // thread 0: the item after the next one (the number has arrived with the row loads)
+    if (threadIdx.x == 0 && code >= 0) code_after = code_of(ticket);
     RMW_T(3);  // next item's entries (and with them, in order, this wave's row loads) have arrived
 #if RNNT_RMW_PACE > 0
     // one wait for all row loads ahead of the first store, then a drain after every RNNT_RMW_PACE stores (grad_span.h)
@@ -355,7 +409,11 @@ __global__ __launch_bounds__(kSpanWaves * 64) __attribute__((amdgpu_waves_per_eu
       const int packed = __float_as_int(cf.w);
       const int lab = (int)(short)(packed & 0xffff);
       if (!(c2 > -INFINITY)) continue;  // an entry that stands for nothing
+#ifdef RNNT_RMW_FAKE_CONTIG
+      float* gp = greg + (size_t)((k * RB + idx) % kRegionRows) * V;
+#else
       float* gp = greg + (size_t)(packed >> 16) * V;
+#endif
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
@@ -383,16 +441,19 @@ __global__ __launch_bounds__(kSpanWaves * 64) __attribute__((amdgpu_waves_per_eu
     // the item's sum of squared gradient elements, stored by the item's identity (deterministic)
     sqsum = group_sum<64>(sqsum);
     if (lane == 0) red[wv] = sqsum;
+    if (threadIdx.x == 0) code_s[cur] = code_after;
     __syncthreads();  // (also: every wavefront is done with this item's coefficients, and the next item's are in place)
+    code_next = code_s[cur];
     if (threadIdx.x == 0) {
       float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < kSpanWaves; ++i) s += red[i];
+      for (int i = 0; i < kRmwWaves; ++i) s += red[i];
       w.partial[(size_t)regid * (SPB + 1) + k] = s;
     }
     RMW_T(5);  // closing barrier
 #ifdef RNNT_RMW_TIMING
     if (threadIdx.x == 0) atomicAdd(&g_rmw_dbg[7], 1ull);
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_rmw_span[1][blockIdx.x] = wall_clock64();
 #endif
     if (code < 0) break;  // (block-uniform)
   }

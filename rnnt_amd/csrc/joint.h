@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void k_joint_prep(const float* __restrict__ f,
     w.hdr->n_count = 0;
     w.hdr->n_items_ready = 0;
     w.hdr->items_ctr = 0ull;
+    w.hdr->rmw_next = 0u;
     w.hdr->partial_off = w.partial_off;
     w.hdr->count_off = w.count_off;
     w.hdr->n_cells = 0;

@@ -38,7 +38,8 @@ struct Header {
   // ... while k_classify_rows runs: low half = work items handed out so far, high half = blocks that have taken
   // theirs (one atomic per block; zero between gradient passes)
   unsigned long long items_ctr;
-  int32_t pad[48];
+  uint32_t rmw_next;      // work items of k_grad_rmw handed out beyond each block's first (zero between gradient passes)
+  int32_t pad[47];
 };
 static_assert(sizeof(Header) == 256, "header is one 256-byte block");
 
@@ -136,9 +137,12 @@ inline int joint_dg_split(int B, int Tp, int U1p, int Vp) {
 // consecutive rows of an utterance (k_grad_span) or at least kMinRmwRows entries of a region of kRegionRows rows
 // (k_grad_rmw).
 constexpr int kMinSpanRows = 8;
-constexpr int kRegionRows = 2048;
+#ifndef RNNT_REGION_ROWS
+#define RNNT_REGION_ROWS 2048
+#endif
+constexpr int kRegionRows = RNNT_REGION_ROWS;
 constexpr int kRegionStride = kRegionRows + 64;  // entries of crec per region: its rows, padded up to a whole work item
-constexpr int kMinRmwRows = 12;
+constexpr int kMinRmwRows = 8;
 inline int ws_regions(int maxT, int maxU1) { return (int)(((size_t)maxT * maxU1 + kRegionRows - 1) / kRegionRows); }
 inline size_t ws_partial_slots(int B, int maxT, int maxU1) {
   const size_t span_blocks = ((size_t)maxT * maxU1 + kMinSpanRows - 1) / kMinSpanRows;

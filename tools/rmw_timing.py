@@ -20,6 +20,9 @@ il = torch.full((B,), T, dtype=torch.int32, device=dev); ll = torch.full((B,), U
 costs = torch.empty(B, device=dev); ws = torch.empty(_lib.workspace_bytes(B, T, U1), dtype=torch.uint8, device=dev)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 buf = (ctypes.c_ulonglong * 8)()
+spans = (ctypes.c_ulonglong * 2048)()
+fs = L.rnnt_mi355x_debug_rmw_spans
+fs.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 for rep in range(3):
     xx = x.clone()
     torch.cuda.synchronize()
@@ -31,3 +34,13 @@ for rep in range(3):
     names = ["first entries", "issue loads", "barrier", "loads arrive", "write phase", "closing"]
     print(f"items {v[7]}  per item (cycles of the 100 MHz counter x10 = ns): " +
           "  ".join(f"{nm} {v[i] / n * 10:.0f}" for i, nm in enumerate(names)))
+    fs(spans)
+    st = [spans[i] for i in range(512)]; en = [spans[1024 + i] for i in range(512)]
+    t0 = min(st)
+    en_s = sorted((e - t0) / 100.0 for e in en)
+    print(f"  blocks start {min(st)-t0:.0f}..{(max(st)-t0)/100:.1f} us; end: first {en_s[0]:.1f} us, 10% {en_s[51]:.1f}, median {en_s[256]:.1f}, 90% {en_s[460]:.1f}, last {en_s[-1]:.1f}")
+    early = sum(1 for x in st if (x - t0) / 100.0 < 20.0)
+    dur = sorted((e - b) / 100.0 for b, e in zip(st, en))
+    print(f"  blocks started within 20 us: {early} of 512; block duration min {dur[0]:.0f} / median {dur[256]:.0f} / max {dur[-1]:.0f} us")
+    late = sorted((x - t0) / 100.0 for x in st if (x - t0) / 100.0 >= 20.0)
+    if late: print(f"  late starts: first {late[0]:.0f} us, median {late[len(late)//2]:.0f}, last {late[-1]:.0f}")
