@@ -250,11 +250,11 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify_rows(const int32_t*
 #endif
 constexpr int kFillWaves = RNNT_FILL_WAVES;
 __global__ __launch_bounds__(kFillWaves * 64) void k_fill_rows(float* __restrict__ grad, size_t gstride, int kib_utt, int row_kib,
-                                                   const uint32_t* __restrict__ rowbits, int row_words) {
+                                                   const uint32_t* __restrict__ rowbits, int row_words, int b0) {
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int kib = (int)blockIdx.x * kFillWaves + wv;  // wave-uniform
   if (kib >= kib_utt) return;
-  const int b = blockIdx.y;
+  const int b = b0 + (int)blockIdx.y;
   const int row = row_kib == 1 ? kib : kib / row_kib;
   const uint32_t word = rowbits[(size_t)b * row_words + (row >> 5)];
   if ((word >> (row & 31)) & 1u) return;

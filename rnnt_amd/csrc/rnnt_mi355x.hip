@@ -468,8 +468,15 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
       const int row_kib = c.V / 256;
       const long long kib_utt = (long long)sg.rows_utt * row_kib;  // < 2^31: rows < 2^31 / B and V <= 4096
       auto fill = [&]() {
-        k_fill_rows<<<dim3((unsigned)((kib_utt + kFillWaves - 1) / kFillWaves), (unsigned)c.B), kFillWaves * 64, 0, st>>>(
-            c.grad, c.gstride, (int)kib_utt, row_kib, c.w.rowbits, c.w.row_words);
+#ifndef RNNT_FILL_SPLIT
+#define RNNT_FILL_SPLIT 1
+#endif
+        const int per = (c.B + RNNT_FILL_SPLIT - 1) / RNNT_FILL_SPLIT;
+        for (int f0 = 0; f0 < c.B; f0 += per) {
+          const int nbf = c.B - f0 < per ? c.B - f0 : per;
+          k_fill_rows<<<dim3((unsigned)((kib_utt + kFillWaves - 1) / kFillWaves), (unsigned)nbf), kFillWaves * 64, 0, st>>>(
+              c.grad, c.gstride, (int)kib_utt, row_kib, c.w.rowbits, c.w.row_words, f0);
+        }
         k_patch_sparse<<<per_region, 256, 0, st>>>(c.grad, c.grad_scale, sp, c.w);
       };
 #if defined(RNNT_SPLIT_OVERLAP)  // experiment: the zero-fill on a second stream underneath the read-modify-write kernel
@@ -536,6 +543,13 @@ int launch_loss_grad(const Call& c, hipStream_t st, void* const* ev) {
   };
   k_init<<<1, 64, 0, st>>>(c.w, 0);
   if (!mark(0)) return RNNT_MI355X_LAUNCH_FAILURE;
+#ifndef RNNT_LSE_SPLIT
+#define RNNT_LSE_SPLIT 1
+#endif
+  if (RNNT_LSE_SPLIT > 1 && !use_small(c, c.logits)) {
+    const int per = (c.B + RNNT_LSE_SPLIT - 1) / RNNT_LSE_SPLIT;
+    for (int l0 = 0; l0 < c.B; l0 += per) launch_lse(c, l0, c.B - l0 < per ? c.B - l0 : per, st);
+  } else
   launch_lse(c, 0, c.B, st);
   if (!mark(1)) return RNNT_MI355X_LAUNCH_FAILURE;
   launch_sweep(c, 0, c.B, st);
@@ -743,6 +757,15 @@ int rnnt_mi355x_debug_rmw_timing(unsigned long long* host8) {
   unsigned long long z[8] = {};
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_rmw_dbg), z, 64) != hipSuccess) return RNNT_MI355X_LAUNCH_FAILURE;
   return RNNT_MI355X_OK;
+}
+// experiment builds only: k_fill_rows alone (rowbits: B * row_words words, row_words = ceil(rows / 64) * 2)
+int rnnt_mi355x_debug_fill(float* grad, size_t gstride, int rows_utt, int row_kib, const uint32_t* rowbits, int B,
+                           void* stream) {
+  const long long kib_utt = (long long)rows_utt * row_kib;
+  const int row_words = (rows_utt + 63) / 64 * 2;
+  k_fill_rows<<<dim3((unsigned)((kib_utt + kFillWaves - 1) / kFillWaves), (unsigned)B), kFillWaves * 64, 0,
+                static_cast<hipStream_t>(stream)>>>(grad, gstride, (int)kib_utt, row_kib, rowbits, row_words, 0);
+  return launch_status();
 }
 int rnnt_mi355x_debug_rmw_spans(unsigned long long* host2048) {
   if (hipDeviceSynchronize() != hipSuccess) return RNNT_MI355X_LAUNCH_FAILURE;

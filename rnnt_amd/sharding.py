@@ -19,6 +19,7 @@ from __future__ import annotations
 
 from typing import List, Sequence
 
+import numpy as np
 import torch
 
 
@@ -54,9 +55,14 @@ MODEL_UNPRUNED = 0.5
 MODEL_LAUNCH_S = 20e-6
 
 
+MODEL_SKEW_BPS = 1.5e12  # re-ordering pass in front of the wide sweep (16 bytes per padded lattice position)
+
+
 def _sweep_step_s(max_u1: int) -> float:
-    return (60e-9 if max_u1 <= 64 else 92e-9 if max_u1 <= 128 else 226e-9 if max_u1 <= 256 else
-            490e-9 if max_u1 <= 512 else 1000e-9)
+    """Seconds per anti-diagonal of the lattice sweeps: one wavefront per direction up to 128 label positions
+    (one or two columns per lane), above that one wavefront per 64 columns, whose pace hardly depends on the
+    width (measured 121-134 ns at 200 positions, 161-173 at 400)."""
+    return 60e-9 if max_u1 <= 64 else 92e-9 if max_u1 <= 128 else 110e-9 + 0.15e-9 * max_u1
 
 
 def shard_seconds(input_lengths: Sequence[int], label_lengths: Sequence[int], indices: Sequence[int], V: int) -> float:
@@ -73,8 +79,19 @@ def shard_seconds(input_lengths: Sequence[int], label_lengths: Sequence[int], in
 def _model_seconds(n: int, t_max: int, u1_max: int, cells: int, V: int) -> float:
     rows = n * t_max * u1_max
     row_bytes = 4.0 * V
+    skew = 16.0 * rows / MODEL_SKEW_BPS if u1_max > 128 else 0.0
     return (cells * row_bytes * (1.0 + MODEL_UNPRUNED) / MODEL_READ_BPS + rows * row_bytes / MODEL_WRITE_BPS +
-            (t_max + u1_max) * _sweep_step_s(u1_max) + MODEL_LAUNCH_S)
+            (t_max + u1_max) * _sweep_step_s(u1_max) + skew + MODEL_LAUNCH_S)
+
+
+def _model_seconds_np(n, t_max, u1_max, cells, V: int):
+    """_model_seconds on arrays (same arithmetic, element by element)."""
+    rows = n * t_max * u1_max
+    row_bytes = 4.0 * V
+    step = np.where(u1_max <= 64, 60e-9, np.where(u1_max <= 128, 92e-9, 110e-9 + 0.15e-9 * u1_max))
+    skew = np.where(u1_max > 128, 16.0 * rows / MODEL_SKEW_BPS, 0.0)
+    return (cells * row_bytes * (1.0 + MODEL_UNPRUNED) / MODEL_READ_BPS + rows * row_bytes / MODEL_WRITE_BPS +
+            (t_max + u1_max) * step + skew + MODEL_LAUNCH_S)
 
 
 def padded_rows(input_lengths: Sequence[int], label_lengths: Sequence[int], indices: Sequence[int]) -> int:
@@ -111,30 +128,33 @@ def partition_bucketed(input_lengths: Sequence[int], label_lengths: Sequence[int
         raise ValueError(f"unknown sort key {sort_by!r}")
     order = sorted(range(n), key=keys[sort_by])
     k = min(n_shards, n) if n else 0
-    # cost[a][b] = modelled time of order[a:b], built incrementally
-    cost = [[0.0] * (n + 1) for _ in range(n + 1)]
-    for a in range(n):
-        t_max = u1_max = cells = 0
-        for b in range(a + 1, n + 1):
-            i = order[b - 1]
-            t, u1 = int(input_lengths[i]), int(label_lengths[i]) + 1
-            t_max, u1_max, cells = max(t_max, t), max(u1_max, u1), cells + t * u1
-            cost[a][b] = _model_seconds(b - a, t_max, u1_max, cells, V)
+    if n == 0:
+        return [[] for _ in range(n_shards)]
+    # cost[a][b] = modelled time of order[a:b] for a < b (whole arrays at once: the triple loop in Python took
+    # seconds for a few hundred utterances, on every rank and every batch)
+    t_sorted = np.asarray([int(input_lengths[i]) for i in order], dtype=np.float64)
+    u_sorted = np.asarray([int(label_lengths[i]) + 1 for i in order], dtype=np.float64)
+    a_idx = np.arange(n)[:, None]
+    b_idx = np.arange(n)[None, :]
+    live = b_idx >= a_idx                                   # entry (a, j): utterance j of the order belongs to runs from a
+    t_run = np.maximum.accumulate(np.where(live, t_sorted[None, :], 0.0), axis=1)
+    u_run = np.maximum.accumulate(np.where(live, u_sorted[None, :], 0.0), axis=1)
+    c_run = np.cumsum(np.where(live, (t_sorted * u_sorted)[None, :], 0.0), axis=1)
+    count = np.where(live, b_idx - a_idx + 1, 0).astype(np.float64)
     inf = float("inf")
-    best = [[inf] * (n + 1) for _ in range(k + 1)]
-    cut = [[0] * (n + 1) for _ in range(k + 1)]
-    if k:
-        best[0][0] = 0.0
+    cost = np.full((n + 1, n + 1), inf)
+    cost[:n, 1:] = np.where(live, _model_seconds_np(count, t_run, u_run, c_run, V), inf)
+    best_prev = np.full(n + 1, inf)
+    best_prev[0] = 0.0
+    cut = np.zeros((k + 1, n + 1), dtype=np.int64)
     for s in range(1, k + 1):
-        for b in range(s, n + 1):
-            for a in range(s - 1, b):
-                v = max(best[s - 1][a], cost[a][b])
-                if v < best[s][b]:
-                    best[s][b], cut[s][b] = v, a
+        m = np.maximum(best_prev[:, None], cost)            # (a, b): slowest shard if the s-th run is order[a:b]
+        cut[s] = np.argmin(m, axis=0)                       # (first minimum: the smallest a, as a scan would find)
+        best_prev = m[cut[s], np.arange(n + 1)]
     shards: List[List[int]] = [[] for _ in range(n_shards)]
     b = n
     for s in range(k, 0, -1):
-        a = cut[s][b]
+        a = int(cut[s][b])
         shards[s - 1] = sorted(order[a:b])
         b = a
     return shards
@@ -147,24 +167,49 @@ def partition_greedy_model(input_lengths: Sequence[int], label_lengths: Sequence
         raise ValueError("n_shards must be >= 1")
     order = sorted(range(len(input_lengths)), key=lambda i: (-int(input_lengths[i]), -int(label_lengths[i]), i))
     shards: List[List[int]] = [[] for _ in range(n_shards)]
+    state = [[0, 0, 0, 0] for _ in range(n_shards)]  # per shard: utterances, max T, max U+1, cells
     for i in order:
-        k = min(range(n_shards), key=lambda s: (shard_seconds(input_lengths, label_lengths, shards[s] + [i], V),
-                                                len(shards[s]), s))
+        t, u1 = int(input_lengths[i]), int(label_lengths[i]) + 1
+
+        def after(s):
+            c, tm, um, ce = state[s]
+            return _model_seconds(c + 1, max(tm, t), max(um, u1), ce + t * u1, V)
+
+        k = min(range(n_shards), key=lambda s: (after(s), len(shards[s]), s))
         shards[k].append(i)
+        c, tm, um, ce = state[k]
+        state[k] = [c + 1, max(tm, t), max(um, u1), ce + t * u1]
     return [sorted(s) for s in shards]
 
 
 def refine_partition(input_lengths: Sequence[int], label_lengths: Sequence[int], shards: List[List[int]], V: int,
-                     max_rounds: int = 200) -> List[List[int]]:
+                     max_rounds: int = 200, max_evals: int = 4000) -> List[List[int]]:
     """Local search on a partition: move one utterance out of the slowest shard,
     or swap it with one of another shard, whenever that lowers the modelled time
     of the slowest shard (first improvement in a fixed scan order, so the result
-    is deterministic)."""
+    is deterministic).  The search stops after max_rounds improvements or
+    max_evals evaluations of the time model -- a count, not a clock: every rank
+    must stop at the same place."""
     shards = [list(s) for s in shards]
     n = len(shards)
+    evals = [0]
+
+    class _Spent(Exception):
+        pass
 
     def sec(s):
+        evals[0] += 1
+        if evals[0] > max_evals:
+            raise _Spent
         return shard_seconds(input_lengths, label_lengths, s, V)
+
+    try:
+        return _refine(shards, n, sec, max_rounds)
+    except _Spent:
+        return [sorted(s) for s in shards]  # (the lists are only ever replaced together, after both evaluations)
+
+
+def _refine(shards, n, sec, max_rounds):
 
     times = [sec(s) for s in shards]
     for _ in range(max_rounds):
@@ -212,6 +257,21 @@ def partition(input_lengths: Sequence[int], label_lengths: Sequence[int], n_shar
     refine_partition."""
     il = [int(v) for v in input_lengths]
     ll = [int(v) for v in label_lengths]
+    key = (tuple(il), tuple(ll), int(n_shards), int(V), method)
+    hit = _PARTITION_CACHE.get(key)
+    if hit is not None:
+        return [list(s) for s in hit]
+    out = _partition(il, ll, n_shards, V, method)
+    if len(_PARTITION_CACHE) >= 16:
+        _PARTITION_CACHE.pop(next(iter(_PARTITION_CACHE)))
+    _PARTITION_CACHE[key] = [list(s) for s in out]
+    return out
+
+
+_PARTITION_CACHE: dict = {}  # the last few batches' partitions (validation sets and fixed-length batches repeat)
+
+
+def _partition(il, ll, n_shards, V, method):
     cands = {
         "cells": lambda: partition_lpt(lattice_cost(il, ll), n_shards),
         "bucketed": lambda: partition_bucketed(il, ll, n_shards, V),
@@ -230,10 +290,17 @@ def partition(input_lengths: Sequence[int], label_lengths: Sequence[int], n_shar
     return refine_partition(il, ll, best, V)
 
 
-def shard_batch(acts, labels, input_lengths, label_lengths, rank: int, world_size: int, method: str = "auto"):
+def shard_batch(acts, labels, input_lengths, label_lengths, rank: int, world_size: int, method: str = "bucketed"):
     """This rank's slice of a batch, cropped to the shard's own max T and U+1
     (each rank pads only to its local maxima).  Returns (acts, labels, in_len,
-    lab_len, indices); acts is a fresh contiguous tensor when cropped."""
+    lab_len, indices); acts is a fresh contiguous tensor when cropped.
+
+    The partition is computed on the host for every batch, on every rank: the
+    default is the length-bucketed cut (a few milliseconds for a hundred
+    utterances, ~0.15 s for 512; on a ragged batch within 1 % of "auto" by the
+    measured slowest rank).  "auto" adds the greedy candidate and a bounded
+    local search and costs tens of milliseconds to half a second; "cells" is
+    the cheapest (sub-millisecond) and pays for padding on ragged batches."""
     il = [int(v) for v in torch.as_tensor(input_lengths).reshape(-1).tolist()]
     ll = [int(v) for v in torch.as_tensor(label_lengths).reshape(-1).tolist()]
     V = int(acts.shape[-1]) if hasattr(acts, "shape") else 1024
@@ -248,6 +315,24 @@ def shard_batch(acts, labels, input_lengths, label_lengths, rank: int, world_siz
     lab = lab.index_select(0, sel.to(lab.device))[:, :u_max].contiguous()
     return (a, lab, torch.tensor([il[i] for i in idx], dtype=torch.int32),
             torch.tensor([ll[i] for i in idx], dtype=torch.int32), idx)
+
+
+def allgather_costs(local_costs: torch.Tensor, indices: Sequence[int], batch: int, group=None) -> torch.Tensor:
+    """Per-utterance costs of the whole batch on every rank, in the batch's own
+    order: each rank contributes the costs of its shard (`indices` = the shard's
+    utterances, as partition returned them).  One all-reduce of `batch` floats
+    into a zero vector -- every slot has exactly one owner, so the sum is a
+    gather that needs no second exchange for the index lists (every rank could
+    derive them, but a sum needs none).  Optional: the training step itself
+    needs only allreduce_scalars."""
+    import torch.distributed as dist
+
+    out = torch.zeros(batch, dtype=local_costs.dtype, device=local_costs.device)
+    if len(indices):
+        out[torch.as_tensor(list(indices), dtype=torch.long, device=out.device)] = local_costs.reshape(-1)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    return out
 
 
 def allreduce_scalars(local: torch.Tensor, group=None, async_op: bool = False):

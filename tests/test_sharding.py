@@ -4,6 +4,7 @@ over gloo with world_size 2.  Per-shard numbers come from the oracle (the HIP
 path needs a GPU; its sharded run is covered in tests/test_gpu_torch_api.py)."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -152,3 +153,65 @@ def test_refinement_never_makes_the_slowest_shard_slower():
     worst = lambda p: max(sharding.shard_seconds(il, ll, s, 512) for s in p)
     assert worst(ref) <= worst(base)
     assert sorted(i for s in ref for i in s) == list(range(40))
+
+
+def test_default_partition_is_cheap_on_the_host():
+    """shard_batch runs on every rank for every batch: its default partition must stay far below a training step
+    (the exhaustive "auto" search is opt-in)."""
+    import time
+    for B, limit in ((128, 0.1), (256, 0.3), (512, 1.0)):
+        rng = np.random.default_rng(B)
+        il = rng.integers(50, 1001, B).tolist()
+        ll = rng.integers(10, 201, B).tolist()
+        sharding._PARTITION_CACHE.clear()
+        t0 = time.perf_counter()
+        parts = sharding.partition(il, ll, 8, 512, "bucketed")
+        dt = time.perf_counter() - t0
+        assert sorted(i for s in parts for i in s) == list(range(B))
+        assert dt < limit, f"B={B}: {dt:.3f} s"
+    # "auto" is bounded by a count of model evaluations, not by a clock (every rank stops at the same place)
+    sharding._PARTITION_CACHE.clear()
+    t0 = time.perf_counter()
+    p1 = sharding.partition(il, ll, 8, 512, "auto")
+    assert time.perf_counter() - t0 < 5.0
+    sharding._PARTITION_CACHE.clear()
+    assert sharding.partition(il, ll, 8, 512, "auto") == p1
+
+
+def test_numpy_bucketed_cut_is_the_exhaustive_one():
+    """The vectorised dynamic programme against a plain triple loop on small batches."""
+    rng = np.random.default_rng(3)
+    for n, k in ((7, 3), (12, 4), (5, 8)):
+        il = rng.integers(50, 1001, n).tolist()
+        ll = rng.integers(0, 201, n).tolist()
+        for key in ("T", "U", "cells"):
+            p = sharding.partition_bucketed(il, ll, k, 512, key)
+            got = max(sharding.shard_seconds(il, ll, s, 512) for s in p)
+            order = sorted(range(n), key={"T": lambda i: (-il[i], -ll[i], i), "U": lambda i: (-ll[i], -il[i], i),
+                                          "cells": lambda i: (-il[i] * (ll[i] + 1), i)}[key])
+            best = {(0, 0): 0.0}
+            for s in range(1, min(k, n) + 1):
+                for b in range(s, n + 1):
+                    best[(s, b)] = min(max(best[(s - 1, a)], sharding.shard_seconds(il, ll, order[a:b], 512))
+                                       for a in range(s - 1, b) if (s - 1, a) in best)
+            assert abs(got - best[(min(k, n), n)]) <= 1e-12 * got
+
+
+def test_allgather_costs_two_ranks_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from rnnt_amd import sharding\n"
+        "dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=2)\n"
+        "r = dist.get_rank()\n"
+        "il = [100, 50, 70, 90, 30]; ll = [10, 5, 7, 9, 3]\n"
+        "idx = sharding.partition(il, ll, 2, 62, 'bucketed')[r]\n"
+        "local = torch.tensor([float(10 * i + 1) for i in idx])\n"
+        "full = sharding.allgather_costs(local, idx, 5)\n"
+        "assert full.tolist() == [1.0, 11.0, 21.0, 31.0, 41.0], full\n"
+        "dist.destroy_process_group()\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", WORLD_SIZE="2", GLOO_SOCKET_IFNAME="lo")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    assert [p.wait(timeout=120) for p in procs] == [0, 0]

@@ -71,6 +71,21 @@ __global__ __launch_bounds__(1024) void k_e(float* g, long long rows, const uint
   }
 }
 
+// R: k_fill_rows as the library has it (two-dimensional grid, one utterance per blockIdx.y)
+__global__ __launch_bounds__(256) void k_r(float* __restrict__ grad, size_t gstride, int kib_utt, int row_kib,
+                                           const uint32_t* __restrict__ rowbits, int row_words) {
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int kib = (int)blockIdx.x * 4 + wv;
+  if (kib >= kib_utt) return;
+  const int b = blockIdx.y;
+  const int row = row_kib == 1 ? kib : kib / row_kib;
+  const uint32_t word = rowbits[(size_t)b * row_words + (row >> 5)];
+  if ((word >> (row & 31)) & 1u) return;
+  const f4v z = {0.f, 0.f, 0.f, 0.f};
+  f4v* dst = reinterpret_cast<f4v*>(grad + (size_t)b * gstride + (size_t)kib * 256) + (threadIdx.x & 63);
+  __builtin_nontemporal_store(z, dst);
+}
+
 template <typename F>
 float timeit(F launch, int reps = 5) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -93,7 +108,7 @@ int main(int argc, char** argv) {
   const long long rows = B * rows_utt, kib_total = rows * row_kib;
   const double gb = kib_total * 1024.0 / 1e9;
   float* g; CK(hipMalloc(&g, kib_total * 1024)); CK(hipMemset(g, 0x3c, kib_total * 1024));
-  uint32_t* bits; CK(hipMalloc(&bits, (rows / 32 + 2) * 4));
+  uint32_t* bits; CK(hipMalloc(&bits, (rows / 32 + 2 + 64 * B) * 4));
   int* list; CK(hipMalloc(&list, rows * 4));
   int* count; CK(hipMalloc(&count, 4));
   printf("tensor %.2f GB = %lld rows of %d KiB\n", gb, rows, row_kib);
@@ -101,6 +116,14 @@ int main(int argc, char** argv) {
 #define C(W) { unsigned n = (unsigned)((kib_total + W - 1) / W); float ms = timeit([&] { k_c<W><<<n, W * 64>>>(g, kib_total); }); \
     printf("no mask, KiB per wave, %2d waves per block                 %8.3f ms %7.1f GB/s\n", W, ms, gb / ms * 1e3); }
   C(1) C(4) C(16)
+  {  // the library's kernel on utterances of rows_utt rows, nothing masked
+    CK(hipMemset(bits, 0, (rows / 32 + 2 + 64 * B) * 4));
+    const int kib_utt = (int)(rows_utt * row_kib), row_words = (int)((rows_utt + 63) / 64 * 2);
+    if ((size_t)B * row_words <= (size_t)(rows / 32 + 2 + 64 * B)) {
+      float ms = timeit([&] { k_r<<<dim3((unsigned)((kib_utt + 3) / 4), (unsigned)B), 256>>>(g, (size_t)kib_utt * 256, kib_utt, row_kib, bits, row_words); });
+      printf("%-56s %8.3f ms %7.1f GB/s\n", "library's k_fill_rows (2-D grid), nothing masked", ms, gb / ms * 1e3);
+    }
+  }
   for (double band : {0.0, 3.5, 29.0, 101.0}) {  // rows of a frame around the diagonal that are NOT filled
     std::vector<uint32_t> h(rows / 32 + 2, 0u);
     std::vector<int> hl;
