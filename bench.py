@@ -178,6 +178,22 @@ def spawn_ranks(n_ranks: int, argv) -> int:
     return 0
 
 
+def counter_bytes_for(config, B, prune_log2, path=None):
+    """HBM counter bytes of profiles/traffic.json for this workload -- only if they were measured on the kernels
+    that are built now (same kernel sources, batch and threshold); {} otherwise, so that a kernel edit without a
+    new profile shows as `traffic: null` instead of an older build's number."""
+    path = path or os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        from rnnt_amd import build as _build
+        ent = json.load(open(path)).get(f"config{config}", {})
+        if (ent.get("B") == B and ent.get("prune_log2") == prune_log2 and
+                ent.get("csrc_sha16") == _build.sources_digest()):
+            return ent
+    except Exception:
+        pass
+    return {}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -460,15 +476,7 @@ def run_rank(args) -> None:
         k_ms[2] = float(np.mean([a.elapsed_time(b) for a, b in ev_grad]))
     pruned_frac = n_pruned / max(cells, 1)
 
-    counter = {}
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and world == 1 and args.logit_scale == 1.0:
-        try:
-            ent = json.load(open(tpath)).get(f"config{args.config}", {})
-            if ent.get("B") == B and ent.get("prune_log2") == prune_log2:
-                counter = ent
-        except Exception:
-            counter = {}
+    counter = counter_bytes_for(args.config, B, prune_log2) if world == 1 and args.logit_scale == 1.0 else {}
 
     def kernel_entry(name, ms, alg_bytes, traffic_model, key):
         e = {"name": name, "ms": float(ms), "algorithmic_bytes": int(alg_bytes),
@@ -505,7 +513,7 @@ def run_rank(args) -> None:
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "backend": (args.backend if world > 1 else None),
+        "backend": (args.backend if multi else None),
         "config": {
             "workload": f"config {args.config}: {cfg['name']}{' (B overridden to %d)' % cfg['B'] if args.batch else ''}, "
                         f"fp32 logits ~ N(0,1){'*%g' % args.logit_scale if args.logit_scale != 1.0 else ''}, "
@@ -572,6 +580,12 @@ def main(argv=None):
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        from rnnt_amd import build as _build   # once, here: the ranks would otherwise all find it stale together
+        if not os.environ.get("RNNT_MI355X_LIB") and os.path.exists(_build.LIB) and _build.needs_build():
+            try:
+                _build.build()
+            except Exception as e:
+                print(f"bench.py: librnnt_mi355x.so is older than its sources and could not be rebuilt ({e})", file=sys.stderr)
         raise SystemExit(spawn_ranks(args.gpus, argv))
     run_rank(args)
 

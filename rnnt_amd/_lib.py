@@ -6,6 +6,7 @@ use of the loss raises.
 from __future__ import annotations
 
 import ctypes
+import subprocess
 import os
 
 from . import build as _build
@@ -96,7 +97,10 @@ def lib() -> ctypes.CDLL:
             except RuntimeError:
                 raise RNNTLibraryError(f"{LIB} is older than its sources ({_build.newer_sources()}) and hipcc is not "
                                        "available to rebuild it") from None
-            _build.build()
+            try:
+                _build.build()
+            except (OSError, subprocess.CalledProcessError) as e:
+                raise RNNTLibraryError(f"{LIB} is older than its sources and rebuilding it failed: {e}") from e
         try:
             handle = ctypes.CDLL(LIB)
         except OSError as e:
@@ -105,6 +109,9 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        if handle.rnnt_mi355x_version() < 0 and os.environ.get("RNNT_MI355X_ALLOW_KNOCKOUT") != "1":
+            raise RNNTLibraryError(f"{LIB} is a timing-experiment build with a piece of a kernel knocked out (its "
+                                   "results are wrong); set RNNT_MI355X_ALLOW_KNOCKOUT=1 to time it")
         _lib = handle
     return _lib
 

@@ -747,7 +747,14 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
 
 extern "C" {
 
-int rnnt_mi355x_version(void) { return 200; }
+// Timing-experiment builds that knock a piece of a kernel out (and so compute wrong results) report a negative
+// version: the Python loader refuses them unless the experiment asks for them by name.
+#if defined(RNNT_SPAN_FAKE_PROLOGUE) || defined(RNNT_RMW_FAKE_CONTIG) || defined(RNNT_DENSE_NO_LOAD) || \
+    defined(RNNT_DENSE_NO_MFMA) || defined(RNNT_DENSE_NO_STORE)
+int rnnt_mi355x_version(void) { return -300; }
+#else
+int rnnt_mi355x_version(void) { return 300; }
+#endif
 
 #ifdef RNNT_RMW_TIMING
 // experiment builds only: reads and clears the per-phase cycle sums of k_grad_rmw

@@ -118,11 +118,12 @@ def joint_dense(x, kernel, bias, activation="linear"):
     K, N = kernel.shape
     if x.shape[-1] != K:
         raise ValueError(f"joint_dense: x has {x.shape[-1]} features, kernel expects {K}")
-    if K > DENSE_MAX_DIM or N > DENSE_MAX_DIM:
+    for name, t in (("x", x), ("kernel", kernel), ("bias", bias)):
+        if t.device.type != "cuda":
+            raise ValueError(f"joint_dense: {name} must live on an MI355X device (there is no CPU path)")
+    if K > DENSE_MAX_DIM or N > DENSE_MAX_DIM:  # wide layers: the vendor GEMM (rocBLAS / hipBLASLt through torch)
         z = torch.matmul(x, kernel) + bias
         return torch.tanh(z) if activation == "tanh" else z
-    if x.device.type != "cuda":
-        raise ValueError("joint_dense: tensors must live on an MI355X device (there is no CPU path)")
     return _DenseFn.apply(x.float().contiguous(), kernel.float().contiguous(), bias.float().contiguous(),
                           1 if activation == "tanh" else 0)
 

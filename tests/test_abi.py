@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_version_and_status_strings():
-    assert _lib.lib().rnnt_mi355x_version() == 200
+    assert _lib.lib().rnnt_mi355x_version() == 300
     assert _lib.status_string(0) == "ok"
     for rc in (1, 2, 3, 4, 99):
         assert _lib.status_string(rc)
@@ -131,6 +131,8 @@ def test_host_side_helpers_without_a_gpu():
         rnnt_amd.joint_log_softmax(torch.zeros(2, 4))
     with pytest.raises(ValueError, match="no CPU path"):
         rnnt_amd.joint_dense(torch.zeros(3, 4), torch.zeros(4, 2), torch.zeros(2))
+    with pytest.raises(ValueError, match="no CPU path"):   # also beyond the widths of the hand-written kernels,
+        rnnt_amd.joint_dense(torch.zeros(3, 200), torch.zeros(200, 300), torch.zeros(300))  # where a library GEMM runs
     with pytest.raises(ValueError):
         rnnt_amd.fc_joint(yt, yp, [(torch.zeros(7, 3), torch.zeros(3))])   # first kernel must have He + Hd rows
     assert rnnt_amd.softmax(torch.zeros(5), is_log=True, axis=0).tolist() == [1.0] * 5   # reference quirk, no GPU needed

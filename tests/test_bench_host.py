@@ -53,3 +53,18 @@ def test_global_lengths_do_not_depend_on_the_rank():
     b = bench.make_lengths(cfg, 0xC0FFEE + 5)
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
     assert a[0].min() >= 50 and a[0].max() <= 1000 and a[1].min() >= 10 and a[1].max() <= 200
+
+
+def test_counter_bytes_are_quoted_only_for_the_kernels_they_were_measured_on(tmp_path):
+    import json
+    from rnnt_amd import build
+    path = tmp_path / "traffic.json"
+    ent = {"B": 64, "prune_log2": -28.0, "csrc_sha16": build.sources_digest(), "step_hbm_bytes": 1.0}
+    path.write_text(json.dumps({"config3": ent}))
+    assert bench.counter_bytes_for(3, 64, -28.0, str(path)) == ent
+    assert bench.counter_bytes_for(3, 32, -28.0, str(path)) == {}
+    assert bench.counter_bytes_for(3, 64, -24.0, str(path)) == {}
+    path.write_text(json.dumps({"config3": dict(ent, csrc_sha16="0" * 16)}))   # profile of an older build
+    assert bench.counter_bytes_for(3, 64, -28.0, str(path)) == {}
+    path.write_text(json.dumps({"config3": {k: v for k, v in ent.items() if k != "csrc_sha16"}}))  # unstamped
+    assert bench.counter_bytes_for(3, 64, -28.0, str(path)) == {}

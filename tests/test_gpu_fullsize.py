@@ -113,6 +113,65 @@ def test_config4_vocab_reduced_batch():
     _subset_parity(before, sub, lab[[1]], il[[1]], ll[[1]], blank, [0], scale=1.0 / 32)
 
 
+def test_config4_full_global_batch():
+    """Config 4 whole: B=32 T=250 U=150 V=4096, 4.95e9 elements (19.8 GB): the second tensor beyond 2^31 elements,
+    rows of 16 KiB (16 chunks per lane)."""
+    B, T, U, V, blank = 32, 250, 150, 4096, 4095
+    x, lab, il, ll = _gpu_batch(B, T, U, V, blank, seed=0xC0FFEE + 4)
+    # copies of utterance 0 just before, just beyond and far beyond the 2^31-element mark (13.9 utterances)
+    for b in (13, 14, 31):
+        x[b].copy_(x[0]); lab[b].copy_(lab[0])
+    picks = [0, 17, 30]
+    before = x[picks].clone()
+    gs = torch.full((B,), 1.0 / B, device=x.device)
+    run = _run(x, lab, il, ll, blank, gs)
+    assert torch.isfinite(run.costs).all()
+    for b in (13, 14, 31):
+        assert torch.equal(run.costs[b], run.costs[0]) and torch.equal(run.x[b], run.x[0])
+    for b in range(B):  # (one utterance at a time: the row sums of the whole tensor would double its footprint)
+        assert run.x[b].sum(-1).abs().max().item() < 1e-6
+    sub = HipRun.__new__(HipRun)
+    sub.costs, sub.x = run.costs[picks], run.x[picks]
+    _subset_parity(before, sub, lab[picks], il[picks], ll[picks], blank, [0, 1, 2], scale=1.0 / B)
+
+
+def test_config5_full_global_batch_padded_to_the_maxima():
+    """Config 5 whole on one GPU: B=128, T in [50,1000], U in [10,200], V=512, padded to 1000 x 201 (52.7 GB,
+    1.3e10 elements): exact zeros beyond every utterance's lengths, duplicates bit-equal across the 2^31 mark,
+    oracle parity on the longest, the shortest and one more utterance."""
+    B, T, U, V, blank = 128, 1000, 200, 512, 511
+    rng = np.random.default_rng(0xC0FFEE + 5)
+    il = rng.integers(50, T + 1, B).astype(np.int32)
+    ll = rng.integers(10, U + 1, B).astype(np.int32)
+    il[7], ll[7] = T, U
+    il[90], ll[90] = 50, 10
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0xC0FFEE + 5)
+    x = torch.empty((B, T, U + 1, V), dtype=torch.float32, device=dev)
+    for b in range(B):
+        x[b].normal_(generator=g)
+    lab = torch.randint(0, V - 1, (B, U), generator=g, device=dev, dtype=torch.int32)
+    # utterance 100 (beyond the 2^31-element mark, which falls inside utterance 20) repeats utterance 3
+    x[100].copy_(x[3]); lab[100].copy_(lab[3]); il[100], ll[100] = il[3], ll[3]
+    longest = int(np.argmax(il.astype(np.int64) * (ll + 1)))
+    shortest = int(np.argmin(il.astype(np.int64) * (ll + 1)))
+    picks = sorted({longest, shortest, 64})
+    before = x[picks].clone()
+    gs = torch.full((B,), 1.0 / B, device=dev)
+    run = _run(x, lab, il, ll, blank, gs)
+    assert torch.isfinite(run.costs).all()
+    assert torch.equal(run.costs[100], run.costs[3]) and torch.equal(run.x[100], run.x[3])
+    for b in range(B):
+        assert not run.x[b, il[b]:].any() and not run.x[b, :, ll[b] + 1:].any()
+        assert run.x[b].sum(-1).abs().max().item() < 1e-6
+    sub = HipRun.__new__(HipRun)
+    sub.costs, sub.x = run.costs[picks], run.x[picks]
+    _subset_parity(before, sub, lab[picks], il[picks], ll[picks], blank, list(range(len(picks))), scale=1.0 / B)
+    del run, x, before
+    torch.cuda.empty_cache()
+
+
 def test_config5_ragged_padded_cells_and_subset_parity():
     """Ragged lengths T in [50,1000], U in [10,200], V=512, B=16 of the 128."""
     B, T, U, V, blank = 16, 1000, 200, 512, 511

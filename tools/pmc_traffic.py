@@ -6,24 +6,34 @@ streaming stores."""
 import csv, glob, json, sys
 from collections import defaultdict
 
+# which step of the path a kernel belongs to (the gradient pass is several kernels: their bytes per launch add up)
+GROUPS = (("k_lse", "k_lse"), ("k_skew_records", "k_sweep"), ("k_sweep", "k_sweep"), ("k_classify_rows", "k_grad"),
+          ("k_fill_rows", "k_grad"), ("k_patch_sparse", "k_grad"), ("k_zero_frames", "k_grad"), ("k_grad", "k_grad"),
+          ("k_init", "k_init"), ("k_reduce_scalars", "k_reduce_scalars"))
+
+
 def per_kernel(dirpath, counter):
-    acc = defaultdict(list)
+    by_name = defaultdict(list)
     for f in glob.glob(dirpath + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != counter: continue
-            n = row["Kernel_Name"].replace("(anonymous namespace)::", "")
-            for key in ("k_grad", "k_lse", "k_sweep", "k_init", "k_reduce_scalars"):
-                if key in n.split("(")[0]:
-                    acc[key].append(float(row["Counter_Value"]))
+            by_name[row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append(float(row["Counter_Value"]))
+    acc = defaultdict(list)  # group -> one mean per kernel of the group
+    for n, vals in by_name.items():
+        for key, group in GROUPS:
+            if key in n:
+                acc[group].append((sum(vals) / len(vals), len(vals)))
+                break
     return acc
 
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in sorted(set(fetch) | set(write)):
-    f = sum(fetch[k]) / max(len(fetch[k]), 1) * 1024 * 2   # KiB -> B, x2 gfx950 correction
-    w = sum(write[k]) / max(len(write[k]), 1) * 1024
-    out[k] = {"launches_seen": len(fetch[k]), "read_bytes_per_launch": f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": f + w}
-    print(f"{k:18s} launches={len(fetch[k]):3d} read={f/1e9:8.3f} GB  write={w/1e9:8.3f} GB  total={(f+w)/1e9:8.3f} GB")
+    f = sum(m for m, _ in fetch[k]) * 1024 * 2   # KiB -> B, x2 gfx950 correction
+    w = sum(m for m, _ in write[k]) * 1024
+    seen = max([n for _, n in fetch[k]] + [0])
+    out[k] = {"launches_seen": seen, "kernels": len(fetch[k]), "read_bytes_per_launch": f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": f + w}
+    print(f"{k:18s} kernels={len(fetch[k])} launches={seen:3d} read={f/1e9:8.3f} GB  write={w/1e9:8.3f} GB  total={(f+w)/1e9:8.3f} GB")
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], "w"), indent=1)

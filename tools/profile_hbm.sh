@@ -1,8 +1,8 @@
-# rocprofv3 kernel stats + HBM counter passes of the default bench workload (config 3) -> gpurun_out/prof_r2/
+# rocprofv3 kernel stats + HBM counter passes of the default bench workload (config 3) -> gpurun_out/prof_c<N>/
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
 CFG=${1:-3}
-OUT=$R/gpurun_out/prof_r2_c$CFG
+OUT=$R/gpurun_out/prof_c$CFG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-legs --steps 10 --warmup 2 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || { tail -5 $OUT/stats.err; exit 1; }
