@@ -46,10 +46,11 @@ namespace {
 #ifndef RNNT_RMW_WAVES  // wavefronts per block of k_grad_rmw
 #define RNNT_RMW_WAVES RNNT_SPAN_WAVES
 #endif
-#ifndef RNNT_RMW_PER_CU  // its resident blocks per compute unit (their registers allow 12 wavefronts)
-#define RNNT_RMW_PER_CU (12 / RNNT_RMW_WAVES)
-#endif
 constexpr int kRmwWaves = RNNT_RMW_WAVES;
+#ifndef RNNT_RMW_WAVES_WIDE  // wavefronts per block for rows of more than 8 KiB (measured at V = 4096: 8 -> 4.00 ms, 6 -> 4.11 ms;
+#define RNNT_RMW_WAVES_WIDE 8  // at V = 1024 the other way round: 2.17 against 2.145 ms)
+#endif
+constexpr int kRmwWavesWide = RNNT_RMW_WAVES_WIDE;
 constexpr int kClassifyIters = 4;  // rows per thread of k_classify_rows
 constexpr int kClassifyBlock = kRegionRows / kClassifyIters;
 static_assert(kRegionRows % (64 * kClassifyIters) == 0 && kClassifyBlock <= 1024 && kRegionRows <= 65536,
@@ -63,6 +64,7 @@ struct SplitGeom {
   int regions_utt;   // regions per utterance
   int rb;            // entries of a region per work item = rows a block of k_grad_rmw takes at a time
   int spb;           // work items per region at most = ceil(kRegionRows / rb)
+  int waves;         // wavefronts per block of k_grad_rmw (rb / waves entries each)
   float prune_log2;
   size_t xstride, gstride;
 };
@@ -181,8 +183,8 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify_rows(const int32_t*
   const int n_items = (total + gm.rb - 1) / gm.rb;
   const int last0 = (n_items - 1) * gm.rb;         // first entry of the last item
   const int n_last = total - last0;                // its entries (n_items > 0)
-  const int ng = gm.rb / kRmwWaves;
-  const int per_wave = (n_last + kRmwWaves - 1) / kRmwWaves;
+  const int ng = gm.rb / gm.waves;
+  const int per_wave = (n_last + gm.waves - 1) / gm.waves;
   int base = 0, sbase = 0;
 #pragma unroll
   for (int it = 0; it < kClassifyIters; ++it) {
@@ -284,9 +286,9 @@ __global__ __launch_bounds__(256) void k_patch_sparse(float* __restrict__ grad, 
 }
 
 // entries per work item and items per region of k_grad_rmw<NC, NG> (one row per wavefront instruction: rows of >= 1 KiB)
-template <int NG>
+template <int NG, int W>
 struct RmwShape {
-  static constexpr int RB = kRmwWaves * NG;
+  static constexpr int RB = W * NG;
   static_assert(RB <= kRegionStride - kRegionRows, "a region's entries are padded to a whole work item inside its stretch");
   static constexpr int SPB = (kRegionRows + RB - 1) / RB;
   static_assert(SPB <= kItemMask + 1 && SPB <= kClassifyBlock, "an item's number inside its region is packed into kItemBits bits; a thread of k_classify_rows per item");
@@ -300,10 +302,10 @@ __device__ unsigned long long g_rmw_span[2][1024];  // wall clock (100 MHz) at w
 #define RMW_T(i) do { } while (0)
 #endif
 
-template <int NC, int NG>
-__global__ __launch_bounds__(kRmwWaves * 64) __attribute__((amdgpu_waves_per_eu(RNNT_SPAN_OCC))) void k_grad_rmw(
+template <int NC, int NG, int W>
+__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(RNNT_SPAN_OCC))) void k_grad_rmw(
     const float* x, float* grad, const float* __restrict__ grad_scale, SplitGeom gm, Ws w) {
-  constexpr int RB = RmwShape<NG>::RB, SPB = RmwShape<NG>::SPB;
+  constexpr int RB = RmwShape<NG, W>::RB, SPB = RmwShape<NG, W>::SPB;
   static_assert(RB >= kMinRmwRows, "the workspace holds one partial-sum slot per kMinRmwRows entries of a region");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int V = gm.V, blank = gm.blank;
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(kRmwWaves * 64) __attribute__((amdgpu_waves_per_eu(
   const int n_items = w.hdr->n_items_ready;
   if ((int)blockIdx.x >= n_items) return;  // (block-uniform)
   __shared__ float4 coef_buf[2][RB];
-  __shared__ float red[kRmwWaves];
+  __shared__ float red[W];
   __shared__ int code_s[2];
   // Work items are handed out by a counter as blocks come free.  Blocks do not run at one pace, and fewer of them
   // may be resident than the grid holds (measured: half of a grid of two per compute unit started when the other
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(kRmwWaves * 64) __attribute__((amdgpu_waves_per_eu(
     if (threadIdx.x == 0) {
       float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < kRmwWaves; ++i) s += red[i];
+      for (int i = 0; i < W; ++i) s += red[i];
       w.partial[(size_t)regid * (SPB + 1) + k] = s;
     }
     RMW_T(5);  // closing barrier

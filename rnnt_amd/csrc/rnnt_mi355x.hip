@@ -451,19 +451,20 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
       sp.prune_log2 = c.prune_log2;
       sp.xstride = c.xstride; sp.gstride = c.gstride;
       const int ng = nchunk <= 256 ? RNNT_SPAN_NG : nchunk <= 512 ? RNNT_SPAN_NG / 2 : RNNT_SPAN_NG / 4;
-      sp.rb = kRmwWaves * ng;
+      sp.waves = nchunk <= 512 ? kRmwWaves : kRmwWavesWide;
+      sp.rb = sp.waves * ng;
       sp.spb = (kRegionRows + sp.rb - 1) / sp.rb;
       const dim3 per_region((unsigned)sp.regions_utt, (unsigned)c.B);
       k_classify_rows<<<per_region, kClassifyBlock, 0, st>>>(c.labels, c.in_len, c.lab_len, c.grad_scale, sp, c.w);
       // a resident grid: two blocks of six wavefronts per compute unit is what their registers allow
       const long long max_items = (long long)c.B * sp.regions_utt * sp.spb;
-      const long long resident = (long long)RNNT_RMW_PER_CU * compute_units();
+      const long long resident = (long long)(12 / sp.waves) * compute_units();  // (their registers allow 12 wavefronts)
       const unsigned grid_rmw = (unsigned)(max_items < resident ? max_items : resident);
-      const dim3 blk(kRmwWaves * 64);
+      const dim3 blk(sp.waves * 64);
       auto rmw = [&]() {
-        if (nchunk <= 256) k_grad_rmw<4, RNNT_SPAN_NG><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
-        else if (nchunk <= 512) k_grad_rmw<8, RNNT_SPAN_NG / 2><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
-        else k_grad_rmw<16, RNNT_SPAN_NG / 4><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
+        if (nchunk <= 256) k_grad_rmw<4, RNNT_SPAN_NG, kRmwWaves><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
+        else if (nchunk <= 512) k_grad_rmw<8, RNNT_SPAN_NG / 2, kRmwWaves><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
+        else k_grad_rmw<16, RNNT_SPAN_NG / 4, kRmwWavesWide><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
       };
       const int row_kib = c.V / 256;
       const long long kib_utt = (long long)sg.rows_utt * row_kib;  // < 2^31: rows < 2^31 / B and V <= 4096
