@@ -213,7 +213,8 @@ def parse_args(argv=None):
     ap.add_argument("--logit-scale", type=float, default=1.0, help="logits ~ N(0,1) * scale")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto", nargs="?", const="on",
                     help="replay each step from a captured HIP graph (kernel times then come from a separate instrumented "
-                         "pass).  auto: on for multi-rank runs, whose per-rank steps are short and launch-bound")
+                         "pass).  auto: on for multi-rank runs, whose per-rank steps are short and launch-bound, and for "
+                         "workloads of less than 1 GB of logits")
     return ap.parse_args(argv)
 
 
@@ -234,7 +235,8 @@ def run_rank(args) -> None:
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     force_pg = bool(os.environ.get("BENCH_FORCE_PROCESS_GROUP"))  # rehearsal of the N > 1 code path with one rank
-    args.graph = args.graph == "on" or (args.graph == "auto" and (world > 1 or force_pg))
+    graph_auto = args.graph == "auto"
+    args.graph = args.graph == "on" or (graph_auto and (world > 1 or force_pg))
     n_dev = torch.cuda.device_count()  # does not initialise the GPU
     if n_dev < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -307,6 +309,8 @@ def run_rank(args) -> None:
     ws = torch.empty(_lib.workspace_bytes(B, T, U1), dtype=torch.uint8, device=dev)
 
     nbytes = master.numel() * 4
+    if graph_auto and nbytes < (1 << 30):  # steps of less than half a millisecond: five launches are 4-16 % of them
+        args.graph = True
     free, _total = torch.cuda.mem_get_info(dev)
     total_steps = args.steps + args.warmup
     # ranks that share a device (gloo rehearsals on a one-GPU box) share its memory: each plans with its share

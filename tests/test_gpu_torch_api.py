@@ -481,3 +481,33 @@ def test_batch_producer_arrays_feed_the_lambda():
     np.testing.assert_allclose(costs.detach().cpu().numpy(), co, rtol=COST_RTOL)
     assert np.abs(t_yt.grad.cpu().numpy() - dt).max() < GRAD_ATOL
     assert np.abs(t_yp.grad.cpu().numpy() - dp).max() < GRAD_ATOL
+
+
+def test_loss_grad_replays_a_graph_for_a_caller_that_keeps_its_buffers():
+    """Small shapes with static buffers: the third call with the same addresses is a graph replay and gives the very
+    bits of the eager call; new addresses run eagerly again; graph=True insists and refuses host lengths."""
+    import rnnt_amd
+    from rnnt_amd import loss as loss_mod
+    B, T, U, V, blank = 4, 30, 9, 62, 39
+    x, lab, il, ll = make_batch(B, T, U, V, blank, seed=77)
+    acts0 = torch.from_numpy(x).to(DEV)
+    labd = torch.from_numpy(lab).to(DEV)
+    ild, lld = torch.from_numpy(il).to(DEV), torch.from_numpy(ll).to(DEV)
+    gs = torch.full((B,), 0.25, device=DEV)
+    ws = torch.empty(rnnt_amd._lib.workspace_bytes(B, T, U + 1), dtype=torch.uint8, device=DEV)
+    loss_mod._GRAPH_CACHE.clear(); loss_mod._GRAPH_SEEN.clear()
+    eager_acts = acts0.clone()
+    eager_costs = rnnt_amd.rnnt_loss_grad_(eager_acts, labd, ild, lld, blank, gs, workspace=ws, graph=False).clone()
+    buf = torch.empty_like(acts0)
+    for i in range(4):
+        buf.copy_(acts0)
+        costs = rnnt_amd.rnnt_loss_grad_(buf, labd, ild, lld, blank, gs, workspace=ws)
+        torch.cuda.synchronize()
+        assert torch.equal(costs, eager_costs) and torch.equal(buf, eager_acts), i
+        assert len(loss_mod._GRAPH_CACHE) == (0 if i == 0 else 1)
+    other = acts0.clone()   # other addresses: eager again, no new graph yet
+    c2 = rnnt_amd.rnnt_loss_grad_(other, labd, ild, lld, blank, gs, workspace=ws)
+    assert torch.equal(c2, eager_costs) and len(loss_mod._GRAPH_CACHE) == 1
+    with pytest.raises(ValueError, match="graph=True"):
+        rnnt_amd.rnnt_loss_grad_(acts0.clone(), labd, il, ll, blank, gs, workspace=ws, graph=True)
+    loss_mod._GRAPH_CACHE.clear(); loss_mod._GRAPH_SEEN.clear()
