@@ -65,6 +65,7 @@ struct SplitGeom {
   int rb;            // entries of a region per work item = rows a block of k_grad_rmw takes at a time
   int spb;           // work items per region at most = ceil(kRegionRows / rb)
   int waves;         // wavefronts per block of k_grad_rmw (rb / waves entries each)
+  int nt;            // the lattice state is larger than the memory-side cache: k_classify_rows reads it past the caches
   float prune_log2;
   size_t xstride, gstride;
 };
@@ -121,9 +122,23 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify_rows(const int32_t*
     const size_t ci = ((size_t)b * w.D + (t + u)) * U1s + u;
     const size_t ci_t = (t + u + 1 < w.D) ? ci + U1s : ci;
     const size_t ci_u = (u + 1 < U1s) ? ci_t + 1 : ci_t;
-    raw[it].a = w.alpha[ci]; raw[it].be = w.beta[ci]; raw[it].be_t = w.beta[ci_t]; raw[it].be_u = w.beta[ci_u];
+    // Lattice state of more than the memory-side cache holds is read past the caches: lines that ordinary loads
+    // leave there are not displaced by the streaming kernels that follow, which then run a quarter slower for
+    // as long as they last (measured: the zero-fill of a 52 GB tensor 5.0-5.9 instead of 7.05 TB/s after 1.2 GB of
+    // ordinary loads here).  Smaller state stays cached: beta is read three times, by neighbouring threads.
+    const float4* rcp = &w.rec[((size_t)b * (gm.maxT + 2) + 1 + t) * maxU1 + u];
     raw[it].ll = ll2;
-    raw[it].rc = w.rec[((size_t)b * (gm.maxT + 2) + 1 + t) * maxU1 + u];
+    if (gm.nt) {  // (block-uniform)
+      raw[it].a = __builtin_nontemporal_load(&w.alpha[ci]);
+      raw[it].be = __builtin_nontemporal_load(&w.beta[ci]);
+      raw[it].be_t = __builtin_nontemporal_load(&w.beta[ci_t]);
+      raw[it].be_u = __builtin_nontemporal_load(&w.beta[ci_u]);
+      const f4v r4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(rcp));
+      raw[it].rc = make_float4(r4[0], r4[1], r4[2], r4[3]);
+    } else {
+      raw[it].a = w.alpha[ci]; raw[it].be = w.beta[ci]; raw[it].be_t = w.beta[ci_t]; raw[it].be_u = w.beta[ci_u];
+      raw[it].rc = *rcp;
+    }
     int lab = 0;
     if (maxU1 > 1) lab = labels[(size_t)b * (maxU1 - 1) + min(u, maxU1 - 2)];
     raw[it].lab = (lab < 0 || lab >= gm.V) ? 0 : lab;

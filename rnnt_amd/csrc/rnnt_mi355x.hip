@@ -452,6 +452,13 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
       sp.xstride = c.xstride; sp.gstride = c.gstride;
       const int ng = nchunk <= 256 ? RNNT_SPAN_NG : nchunk <= 512 ? RNNT_SPAN_NG / 2 : RNNT_SPAN_NG / 4;
       sp.waves = nchunk <= 512 ? kRmwWaves : kRmwWavesWide;
+      {  // alpha, beta and the records of the batch against the 256 MiB of the memory-side cache
+        const size_t state = (size_t)c.B * ((size_t)c.w.D * c.w.U1s * 16 + (size_t)(c.maxT + 2) * c.maxU1 * 16);
+        sp.nt = state > (192u << 20);
+#ifdef RNNT_FORCE_NT
+        sp.nt = RNNT_FORCE_NT;
+#endif
+      }
       sp.rb = sp.waves * ng;
       sp.spb = (kRegionRows + sp.rb - 1) / sp.rb;
       const dim3 per_region((unsigned)sp.regions_utt, (unsigned)c.B);
