@@ -46,6 +46,12 @@ namespace {
 #ifndef RNNT_RMW_WAVES  // wavefronts per block of k_grad_rmw
 #define RNNT_RMW_WAVES RNNT_SPAN_WAVES
 #endif
+#ifndef RNNT_RMW_NG  // rows per wavefront and work item of k_grad_rmw for rows of up to 4 KiB (a multiple of 4)
+#define RNNT_RMW_NG RNNT_SPAN_NG
+#endif
+#ifndef RNNT_RMW_OCC  // wavefronts per SIMD its register allocation must leave room for
+#define RNNT_RMW_OCC RNNT_SPAN_OCC
+#endif
 constexpr int kRmwWaves = RNNT_RMW_WAVES;
 #ifndef RNNT_RMW_WAVES_WIDE  // wavefronts per block for rows of more than 8 KiB (measured at V = 4096: 8 -> 4.00 ms, 6 -> 4.11 ms;
 #define RNNT_RMW_WAVES_WIDE 8  // at V = 1024 the other way round: 2.17 against 2.145 ms)
@@ -318,7 +324,7 @@ __device__ unsigned long long g_rmw_span[2][1024];  // wall clock (100 MHz) at w
 #endif
 
 template <int NC, int NG, int W>
-__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(RNNT_SPAN_OCC))) void k_grad_rmw(
+__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(RNNT_RMW_OCC))) void k_grad_rmw(
     const float* x, float* grad, const float* __restrict__ grad_scale, SplitGeom gm, Ws w) {
   constexpr int RB = RmwShape<NG, W>::RB, SPB = RmwShape<NG, W>::SPB;
   static_assert(RB >= kMinRmwRows, "the workspace holds one partial-sum slot per kMinRmwRows entries of a region");

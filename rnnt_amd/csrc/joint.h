@@ -444,64 +444,13 @@ struct DfCorr {
   int maxU1, nub, blank_pos;  // blank_pos = U_b + 1: the chain entry that stands for the blank
 };
 
+// Epilogue of a gradient contraction: the element-wise factor, the blank / label chains (CORR), the stores.
 template <int NT, bool CORR>
-__device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, int a_chunks, int kbeg, int kmax,
-                                              const float* __restrict__ b_base, const float* __restrict__ e_base,
-                                              int Vp, int m0, int n0, int m_real, int V, float* __restrict__ out,
-                                              bool vec_ok, int lane, const DfCorr& dc) {
+__device__ __forceinline__ void joint_grad_epilogue(f16v (&acc)[NT], const int (&hd)[NT], const float* __restrict__ e_base,
+                                                    int Vp, int m0, int col, int m_real, int V, float* __restrict__ out,
+                                                    bool vec_ok, int lane, const DfCorr& dc) {
   typedef typename FVec<NT>::type vecn;
-  const int l32 = lane & 31, h = lane >> 5, chunks = Vp >> 3;
-  const int col = n0 + NT * l32;
-  int hd[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) hd[j] = CORR ? dc.head[col + j] : -1;  // col + j < Vp
-  const float* ap = a_base + tiled_off(m0 + l32, 4 * h, a_chunks);
-  const float* bp = b_base + tiled_off(4 * h, col, chunks);  // + 8 floats per row, + 256*chunks per 32 rows
-  f16v acc[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  auto b_off = [&](int k0, int i) { return ((size_t)(k0 >> 5) * chunks << 8) + (((k0 & 31) + i) << 3); };
-  // A ring of D register sets (8 columns of A and 8 rows of Bm each): a set is re-loaded right after the 4*NT MFMAs
-  // that consumed it, so its loads have the MFMAs of the other D-1 sets to come back.  (Written as "load the next
-  // set, then multiply this one" with two sets, the compiler moved the loads below the MFMAs they were meant to
-  // overlap; a load that follows the last use of its own registers cannot be moved up, and the scheduling barrier
-  // keeps it from moving down.)
-#ifndef RNNT_JOINT_RING
-#define RNNT_JOINT_RING 3
-#endif
-  constexpr int D = (NT == 4 && CORR) ? 2 : RNNT_JOINT_RING;  // (the epilogue of that form needs the registers)
-  f4v a[D];
-  vecn bv[D][4];
-  auto load_set = [&](int k0, f4v& av, vecn (&bw)[4]) {
-    av = ld4(ap + ((size_t)(k0 >> 3) << 8));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bw[i] = *reinterpret_cast<const vecn*>(bp + b_off(k0, i));
-  };
-  auto mfma_set = [&](const f4v& av, const vecn (&bw)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], fvec_get<NT>(bw[i], j), acc[j], 0, 0, 0);
-  };
-  if (kmax > kbeg) {  // K range [kbeg, kmax), both multiples of 8
-    const int klast = kmax - 8;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      load_set(min(kbeg + 8 * d, klast), a[d], bv[d]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    for (int k0 = kbeg; k0 < kmax; k0 += 8 * D) {
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        if (k0 + 8 * d < kmax) mfma_set(a[d], bv[d]);  // uniform
-        load_set(min(k0 + 8 * (d + D), klast), a[d], bv[d]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
+  const int chunks = Vp >> 3;
   // all 16 element-wise factors are loaded before the first store (rows past the end re-read the last one);
   // requesting them ahead of the K loop measured slower (64 more registers, fewer resident waves)
   vecn e[16];
@@ -584,6 +533,67 @@ __device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, 
   }
 }
 
+template <int NT, bool CORR>
+__device__ __forceinline__ void joint_grad_mm(const float* __restrict__ a_base, int a_chunks, int kbeg, int kmax,
+                                              const float* __restrict__ b_base, const float* __restrict__ e_base,
+                                              int Vp, int m0, int n0, int m_real, int V, float* __restrict__ out,
+                                              bool vec_ok, int lane, const DfCorr& dc) {
+  typedef typename FVec<NT>::type vecn;
+  const int l32 = lane & 31, h = lane >> 5, chunks = Vp >> 3;
+  const int col = n0 + NT * l32;
+  int hd[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) hd[j] = CORR ? dc.head[col + j] : -1;  // col + j < Vp
+  const float* ap = a_base + tiled_off(m0 + l32, 4 * h, a_chunks);
+  const float* bp = b_base + tiled_off(4 * h, col, chunks);  // + 8 floats per row, + 256*chunks per 32 rows
+  f16v acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  auto b_off = [&](int k0, int i) { return ((size_t)(k0 >> 5) * chunks << 8) + (((k0 & 31) + i) << 3); };
+  // A ring of D register sets (8 columns of A and 8 rows of Bm each): a set is re-loaded right after the 4*NT MFMAs
+  // that consumed it, so its loads have the MFMAs of the other D-1 sets to come back.  (Written as "load the next
+  // set, then multiply this one" with two sets, the compiler moved the loads below the MFMAs they were meant to
+  // overlap; a load that follows the last use of its own registers cannot be moved up, and the scheduling barrier
+  // keeps it from moving down.)
+#ifndef RNNT_JOINT_RING
+#define RNNT_JOINT_RING 3
+#endif
+  constexpr int D = (NT == 4 && CORR) ? 2 : RNNT_JOINT_RING;  // (the epilogue of that form needs the registers)
+  f4v a[D];
+  vecn bv[D][4];
+  auto load_set = [&](int k0, f4v& av, vecn (&bw)[4]) {
+    av = ld4(ap + ((size_t)(k0 >> 3) << 8));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bw[i] = *reinterpret_cast<const vecn*>(bp + b_off(k0, i));
+  };
+  auto mfma_set = [&](const f4v& av, const vecn (&bw)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], fvec_get<NT>(bw[i], j), acc[j], 0, 0, 0);
+  };
+  if (kmax > kbeg) {  // K range [kbeg, kmax), both multiples of 8
+    const int klast = kmax - 8;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      load_set(min(kbeg + 8 * d, klast), a[d], bv[d]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int k0 = kbeg; k0 < kmax; k0 += 8 * D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (k0 + 8 * d < kmax) mfma_set(a[d], bv[d]);  // uniform
+        load_set(min(k0 + 8 * (d + D), klast), a[d], bv[d]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  joint_grad_epilogue<NT, CORR>(acc, hd, e_base, Vp, m0, col, m_real, V, out, vec_ok, lane, dc);
+}
+
 // d f(t,v) = F(t,v) * sum_u C(t,u) G(u,v): M = frames, N = vocabulary, K = label positions.
 // CORR: the blank / label terms are subtracted in the epilogue (k_joint_labelmap has run); otherwise
 // k_joint_corr_f follows.
@@ -631,6 +641,126 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   joint_grad_mm<NT, false>(w.Cut + cb, w.Tp >> 3, kbeg, kend, w.Fp + (size_t)b * w.Tp * w.Vp,
                            w.Gp + (size_t)b * w.U1p * w.Vp, w.Vp, mt.m0, mt.n0, jg.maxU1, jg.V, out, vec_ok,
                            threadIdx.x & 63, DfCorr{});
+}
+
+// ---------------------------------------------------------------------------
+// The d g contraction with the N-contiguous operand shared by a block through LDS (strips of 128 columns).
+// Per step of 8 along K a wavefront of the register-fed form loads 1 KiB of A and 4 KiB of Bm for 16 matrix
+// instructions, and the four wavefronts of a compute unit's SIMDs ask the path from L2 for more bytes than 256
+// cycles of matrix work leave time for.  Here a block is four wavefronts on four CONSECUTIVE row tiles of ONE
+// column strip: Bm's 8 x 128 piece of a step is fetched once per block (a float4
+// per thread, two steps ahead, through registers into one of two LDS buffers, one barrier per step) and read by
+// each wavefront with four 16-byte LDS loads; A stays per wavefront, straight from memory, in a ring of three.
+// LDS layout of a piece: [16 chunks of 8 columns][8 rows][8 columns], chunks 68 floats apart (the 16 lanes pairs of
+// a wavefront that read the same row of different chunks would otherwise meet in one bank).
+// Measured at B=64, T=400, U=100, V=1024: d g (50 steps along the frames, 4 row tiles = one full block) 76.5 -> 72.1
+// us; the same for d f (13 steps along the label positions, an epilogue as large as the loop, 13 row tiles = every
+// fourth block with three idle wavefronts) 121.6 -> 146.2 us: d f keeps the register-fed form, and so does d g
+// when its row tiles do not fill whole blocks (U+1 = 151: five tiles).
+// ---------------------------------------------------------------------------
+constexpr int kMmLdsChunk = 68;                      // floats between two column chunks of a staged piece
+constexpr int kMmLdsPiece = 16 * kMmLdsChunk;        // floats per staged piece (8 x 128 of Bm)
+
+// K range [kbeg, kmax) is the same for the whole block; `live` = this wavefront's row tile exists.
+__device__ __forceinline__ void joint_mm_loop_lds(f16v (&acc)[4], const float* __restrict__ ap, int kbeg, int kmax,
+                                                  const float* __restrict__ b_strip, int chunks, float* __restrict__ lds,
+                                                  bool live, int lane) {
+  const int l32 = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x;
+  // this thread's float4 of a piece: chunk tid / 16, float4 tid % 16 of the chunk's 64 floats (row (tid % 16) / 2)
+  const float* bsrc = b_strip + ((size_t)(tid >> 4) << 8) + ((tid & 15) << 2);
+  float* bdst = lds + (tid >> 4) * kMmLdsChunk + ((tid & 15) << 2);
+  const float* brd = lds + (l32 >> 1) * kMmLdsChunk + (4 * h) * 8 + 4 * (l32 & 1);
+  auto b_piece = [&](int k0) { return ld4(bsrc + (((size_t)(k0 >> 5) * chunks) << 8) + ((k0 & 31) << 3)); };
+  const int nsteps = (kmax - kbeg) >> 3;
+  if (nsteps <= 0) return;  // (block-uniform)
+  const int klast = kmax - 8;
+  f4v a[3];
+  f4v stage[2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) a[d] = ld4(ap + ((size_t)(min(kbeg + 8 * d, klast) >> 3) << 8));
+  {
+    const f4v first = b_piece(kbeg);
+    stage[1] = b_piece(min(kbeg + 8, klast));
+    *reinterpret_cast<f4v*>(bdst) = first;
+  }
+  __syncthreads();
+  // step s reads LDS buffer s % 2; stage[s % 2] receives the piece of step s + 2, stage[(s + 1) % 2] (the piece of
+  // step s + 1, requested a step ago) goes into buffer (s + 1) % 2 at the end of step s
+  for (int s0 = 0; s0 < nsteps; s0 += 6) {  // 6 = lcm of the ring of A (3) and the two buffers
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      const int s = s0 + d;
+      if (s < nsteps) {  // (block-uniform)
+        const int k0 = kbeg + 8 * s;
+        stage[d & 1] = b_piece(min(k0 + 16, klast));
+        const float* rd = brd + (d & 1) * kMmLdsPiece;
+        f4v bw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bw[i] = *reinterpret_cast<const f4v*>(rd + i * 8);
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d % 3][i], bw[i][j], acc[j], 0, 0, 0);
+        }
+        a[d % 3] = ld4(ap + ((size_t)(min(k0 + 24, klast) >> 3) << 8));
+        *reinterpret_cast<f4v*>(bdst + ((d + 1) & 1) * kMmLdsPiece) = stage[(d + 1) & 1];
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// Block -> (utterance, column strip, group of four row tiles); wavefront w takes row tile 4 * group + w.
+struct MmBlockTile {
+  int b, strip, m_first, m0;  // m_first: first row of the group; m0: this wavefront's (clamped to the last tile)
+  bool live;
+};
+__device__ __forceinline__ MmBlockTile mm_block_tile(int m_tiles, int strips) {
+  MmBlockTile t;
+  const int groups = (m_tiles + 3) >> 2;
+  int id = blockIdx.x;
+  const int grp = id % groups;
+  id /= groups;
+  t.strip = id % strips;
+  t.b = id / strips;
+  const int mine = 4 * grp + (int)(threadIdx.x >> 6);
+  t.live = mine < m_tiles;
+  t.m_first = 128 * grp;
+  t.m0 = 32 * min(mine, m_tiles - 1);
+  return t;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_joint_dg_mm_lds(
+    float* __restrict__ dg, const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len, JointGeom jg, Ws w,
+    bool vec_ok) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kMmLdsPiece];
+  const int ks = w.dg_split;
+  MmBlockTile t = mm_block_tile(w.U1p / 32, w.Vp / 128);  // t.b counts (slice, utterance) pairs, slices slowest
+  const int slice_i = t.b / jg.B, b = t.b - slice_i * jg.B;
+  const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5;
+  int T, U;
+  utt_dims(in_len, lab_len, b, jg.maxT, jg.maxU1, T, U);
+  const int kmax = (t.m_first <= U) ? (T + 7) & ~7 : 0;  // C is zero in frames >= T_b and columns > U_b
+  const int slice = (kmax + 16 * ks - 1) / (16 * ks) * 16;
+  const int kbeg = min(kmax, slice_i * slice), kend = min(kmax, kbeg + slice);
+  const int chunks = w.Vp >> 3, n0 = 128 * t.strip, col = n0 + 4 * l32;
+  int hd[4] = {-1, -1, -1, -1};
+  f16v acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const float* a_base = w.Cut + (size_t)b * w.Tp * w.U1p;
+  const float* b_base = w.Fp + (size_t)b * w.Tp * w.Vp;
+  joint_mm_loop_lds(acc, a_base + tiled_off(t.m0 + l32, 4 * h, w.Tp >> 3), kbeg, kend, b_base + ((size_t)(n0 >> 3) << 8), chunks,
+                    lds, t.live, lane);
+  if (!t.live) return;
+  float* out = ks > 1 ? w.dgpart + ((size_t)slice_i * jg.B + b) * jg.maxU1 * jg.V : dg + (size_t)b * jg.maxU1 * jg.V;
+  joint_grad_epilogue<4, false>(acc, hd, w.Gp + (size_t)b * w.U1p * w.Vp, w.Vp, t.m0, col, jg.maxU1, jg.V, out, vec_ok, lane,
+                                DfCorr{});
 }
 
 // Blank and label terms of d f as a pass of their own (small vocabularies, where labels repeat so often that the

@@ -450,7 +450,7 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
       sp.regions_utt = ws_regions(c.maxT, c.maxU1);
       sp.prune_log2 = c.prune_log2;
       sp.xstride = c.xstride; sp.gstride = c.gstride;
-      const int ng = nchunk <= 256 ? RNNT_SPAN_NG : nchunk <= 512 ? RNNT_SPAN_NG / 2 : RNNT_SPAN_NG / 4;
+      const int ng = nchunk <= 256 ? RNNT_RMW_NG : nchunk <= 512 ? RNNT_RMW_NG / 2 : RNNT_RMW_NG / 4;
       sp.waves = nchunk <= 512 ? kRmwWaves : kRmwWavesWide;
       {  // alpha, beta and the records of the batch against the 256 MiB of the memory-side cache
         const size_t state = (size_t)c.B * ((size_t)c.w.D * c.w.U1s * 16 + (size_t)(c.maxT + 2) * c.maxU1 * 16);
@@ -465,13 +465,16 @@ void launch_grad(const Call& c, int b0, int nb, hipStream_t st) {
       k_classify_rows<<<per_region, kClassifyBlock, 0, st>>>(c.labels, c.in_len, c.lab_len, c.grad_scale, sp, c.w);
       // a resident grid: two blocks of six wavefronts per compute unit is what their registers allow
       const long long max_items = (long long)c.B * sp.regions_utt * sp.spb;
-      const long long resident = (long long)(12 / sp.waves) * compute_units();  // (their registers allow 12 wavefronts)
+#ifndef RNNT_RMW_PER_CU  // blocks of the resident grid per compute unit (their registers allow 12 wavefronts)
+#define RNNT_RMW_PER_CU (12 / sp.waves)
+#endif
+      const long long resident = (long long)(RNNT_RMW_PER_CU) * compute_units();
       const unsigned grid_rmw = (unsigned)(max_items < resident ? max_items : resident);
       const dim3 blk(sp.waves * 64);
       auto rmw = [&]() {
-        if (nchunk <= 256) k_grad_rmw<4, RNNT_SPAN_NG, kRmwWaves><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
-        else if (nchunk <= 512) k_grad_rmw<8, RNNT_SPAN_NG / 2, kRmwWaves><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
-        else k_grad_rmw<16, RNNT_SPAN_NG / 4, kRmwWavesWide><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
+        if (nchunk <= 256) k_grad_rmw<4, RNNT_RMW_NG, kRmwWaves><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
+        else if (nchunk <= 512) k_grad_rmw<8, RNNT_RMW_NG / 2, kRmwWaves><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
+        else k_grad_rmw<16, RNNT_RMW_NG / 4, kRmwWavesWide><<<grid_rmw, blk, 0, st>>>(c.logits, c.grad, c.grad_scale, sp, c.w);
       };
       const int row_kib = c.V / 256;
       const long long kib_utt = (long long)sg.rows_utt * row_kib;  // < 2^31: rows < 2^31 / B and V <= 4096
@@ -731,6 +734,12 @@ int launch_joint_backward(const JointCall& c, const float* grad_scale, float* df
   } else {
     if (fold) k_joint_df_mm<4, true><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
     else k_joint_df_mm<4, false><<<mm_blocks(jg.B, mt, ns), 256, 0, st>>>(df, c.in_len, c.lab_len, jg, w, vf);
+#ifndef RNNT_JOINT_NO_LDS
+    if (mu % 4 == 0) {  // whole blocks of four row tiles: the vocabulary-side operand goes through LDS once per block
+      const unsigned dg_blocks = (unsigned)((long long)jg.B * w.dg_split * ns * (mu / 4));
+      k_joint_dg_mm_lds<<<dg_blocks, 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
+    } else
+#endif
     k_joint_dg_mm<4><<<mm_blocks(jg.B * w.dg_split, mu, ns), 256, 0, st>>>(dg, c.in_len, c.lab_len, jg, w, vg);
   }
   if (!fold) {

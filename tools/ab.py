@@ -45,7 +45,7 @@ for r in range(a.rounds + 1):
         e[0].record()
         rc = L.rnnt_mi355x_forward(p(buf), p(labels), p(il), p(ll), *meta, p(costs), p(ws), sp)
         e[1].record()
-        rc |= L.rnnt_mi355x_backward_inplace(p(buf), p(labels), p(il), p(ll), *meta, p(gs), p(ws), sp)
+        rc |= L.rnnt_mi355x_backward_inplace(p(buf), p(labels), p(il), p(ll), *meta, p(gs), p(ws), sp, float("nan"))
         e[2].record()
         torch.cuda.synchronize()
         assert rc == 0
@@ -53,7 +53,7 @@ for r in range(a.rounds + 1):
             buf.copy_(master)
             f0 = torch.cuda.Event(enable_timing=True); f1 = torch.cuda.Event(enable_timing=True)
             f0.record()
-            rc = L.rnnt_mi355x_loss_grad(p(buf), p(labels), p(il), p(ll), *meta, p(gs), p(costs), p(ws), sp)
+            rc = L.rnnt_mi355x_loss_grad(p(buf), p(labels), p(il), p(ll), *meta, p(gs), p(costs), p(ws), sp, float("nan"))
             f1.record(); torch.cuda.synchronize(); assert rc == 0
             fused.setdefault(name, []).append(f0.elapsed_time(f1))
         if r == 0:

@@ -21,12 +21,12 @@ sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 meta = (B, T, U1, V, blank)
 def fused():
     rc = L.rnnt_mi355x_joint_forward(p(f), T * V, p(g), p(lab), p(il), p(ll), *meta, p(costs), p(ws), sp)
-    rc |= L.rnnt_mi355x_joint_backward(p(f), T * V, p(g), p(lab), p(il), p(ll), *meta, p(gs), p(df), T * V, p(dg), p(ws), sp)
+    rc |= L.rnnt_mi355x_joint_backward(p(f), T * V, p(g), p(lab), p(il), p(ll), *meta, p(gs), p(df), T * V, p(dg), p(ws), sp, float("nan"))
     assert rc == 0
 ws2 = torch.empty(_lib.workspace_bytes(B, T, U1), dtype=torch.uint8, device=dev)
 def materialised():
     acts = f.unsqueeze(2) + g.unsqueeze(1)
-    rc = L.rnnt_mi355x_loss_grad(p(acts), p(lab), p(il), p(ll), *meta, p(gs), p(costs), p(ws2), sp)
+    rc = L.rnnt_mi355x_loss_grad(p(acts), p(lab), p(il), p(ll), *meta, p(gs), p(costs), p(ws2), sp, float("nan"))
     assert rc == 0
     return acts.sum(2), acts.sum(1)
 def timeit(fn):

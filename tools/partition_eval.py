@@ -40,7 +40,7 @@ def time_shard(L, dev, il_h, ll_h, V, blank, scale_b, reps):
         buf.copy_(master)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        rc = L.rnnt_mi355x_loss_grad(p(buf), p(labels), p(il), p(ll), B, T, U1, V, blank, p(gs), p(costs), p(ws), sp)
+        rc = L.rnnt_mi355x_loss_grad(p(buf), p(labels), p(il), p(ll), B, T, U1, V, blank, p(gs), p(costs), p(ws), sp, float("nan"))
         rc |= L.rnnt_mi355x_reduce_scalars(p(costs), B, p(ws), p(scal), sp)
         e1.record()
         torch.cuda.synchronize()

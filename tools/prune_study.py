@@ -49,7 +49,7 @@ def main():
                 buf.copy_(master)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                rc = L.rnnt_mi355x_loss_grad(p(buf), p(labels), p(il), p(ll), B, T, U1, V, blank, None, p(costs), p(ws), sp)
+                rc = L.rnnt_mi355x_loss_grad(p(buf), p(labels), p(il), p(ll), B, T, U1, V, blank, None, p(costs), p(ws), sp, float("nan"))
                 e1.record()
                 torch.cuda.synchronize()
                 assert rc == 0

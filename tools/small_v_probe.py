@@ -15,6 +15,6 @@ for a in (sys.argv[1:] or ["32", "40", "62", "64"]):
     ws = torch.empty(_lib.workspace_bytes(B, T, U + 1), dtype=torch.uint8, device=dev)
     for _ in range(5):
         x.copy_(master)   # the gradient overwrites the logits: same input every time
-        assert L.rnnt_mi355x_loss_grad(p(x), p(lab), p(il), p(ll), B, T, U + 1, V, 0, None, p(costs), p(ws), None) == 0
+        assert L.rnnt_mi355x_loss_grad(p(x), p(lab), p(il), p(ll), B, T, U + 1, V, 0, None, p(costs), p(ws), None, float("nan")) == 0
     torch.cuda.synchronize()
     print(B, T, U, V, x.numel() * 4 / 1e6, "MB")
