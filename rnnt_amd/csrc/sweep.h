@@ -88,9 +88,13 @@ __device__ __forceinline__ void store_row(double* base, int row, int u0, const d
 }
 
 // log2(2^x + 2^y) with the sum in float64 and the correction term in float32
+// (the maximum as the bare instruction: fmax() first re-quiets an operand that came out of a DPP move -- one more
+// instruction on a loop that costs what it issues; neither operand is ever a NaN here)
 __device__ __forceinline__ double log2_add(double x, double y) {
   const float df = (float)(x - y);
-  return fmax(x, y) + (double)fast_log2(1.0f + fast_exp2(-fabsf(df)));
+  double m;
+  asm("v_max_f64 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y));
+  return m + (double)fast_log2(1.0f + fast_exp2(-fabsf(df)));
 }
 
 template <int K>
@@ -249,11 +253,19 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
 //    cell), so a wavefront's 64 cells of a diagonal are 512 contiguous bytes instead of 64 cache lines -- the
 //    compute unit's vector cache takes a line per cycle whichever wavefront asks;
 //  * the one number per diagonal that a wavefront needs from its neighbour goes through LDS in bands of
-//    kSweepBand diagonals, and the wavefronts run one band apart (rank r works on band s - r in pass s), so a
-//    band's values were all written in the pass before: one block barrier per band, nothing is polled.
+//    kSweepBand diagonals, and the wavefronts run one band apart (rank r meets r barriers before its first band,
+//    then one after each band), so a band's values were all written before the barrier in front of it: one block
+//    barrier per band, nothing is polled.
 // ---------------------------------------------------------------------------
 // grid (U1s / 256 or 1, Dp / kSkewRows, B), blocks of min(U1s, 256) threads: a thread fills column u of kSkewRows
 // diagonals (one diagonal per block is a launch of 10^5 blocks of a few instructions each: dispatch-bound)
+// The barrier between two bands of k_sweep_wide: the hand-over values in LDS are all it orders (no wavefront reads
+// global memory another one of the block wrote), so it waits for LDS only -- __syncthreads() would also wait for the
+// wavefront's stores and for its ring of loads, and the loop would drain them once per band.
+__device__ __forceinline__ void band_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 constexpr int kSkewRows = 16;  // divides kSweepBand, hence Dp
 __global__ __launch_bounds__(256) void k_skew_records(Ws w, int maxT, int maxU1) {
   const int U1s = w.U1s;
@@ -275,9 +287,29 @@ __global__ __launch_bounds__(256) void k_skew_records(Ws w, int maxT, int maxU1)
 __global__ __launch_bounds__(1024) void k_sweep_wide(Ws w, float* __restrict__ costs, const int32_t* __restrict__ in_len,
                                                      const int32_t* __restrict__ lab_len, int B, int maxT, int maxU1,
                                                      int b0) {
-  constexpr int P = 16, DB = kSweepBand;
-  static_assert(DB % P == 0 && DB <= 64 && DB % kSkewRows == 0, "a band is whole groups of the ring and fits one lane per diagonal");
-  __shared__ double hand[16][2][DB];  // [boundary between rank r and r + 1][band parity][diagonal of the band]
+#ifndef RNNT_WIDE_P
+#define RNNT_WIDE_P 32
+#endif
+  constexpr int P = RNNT_WIDE_P, DB = kSweepBand;
+  static_assert(DB % P == 0 && DB >= P && DB % kSkewRows == 0, "a band is whole groups of the ring");
+  // Two things set a diagonal's time here, and both had to go (T=500, B=32, ns per diagonal at U+1 = 64 / 101 / 200 /
+  // 400, i.e. 1 / 2 / 4 / 8 wavefronts: 101 / 107 / 117 / 176 before, 67 / 73 / 82 / 160 now; k_sweep<1> runs 61):
+  //  * the re-ordered log-probs are read once each, from wherever k_skew_records left them (another XCD's L2, the
+  //    memory-side cache): ~1.6 us a load, so a ring of 16 diagonals bounds a diagonal at 100 ns whatever else it
+  //    does.  The ring is 32 deep (64 would overflow the 6-bit vmcnt the waits are counted in: 136 ns), and the
+  //    barrier between bands waits for LDS only, in a loop that holds nothing but whole bands -- the waits stay
+  //    counted and the ring is never drained;
+  //  * one wavefront issues an instruction every ~2.2 ns whatever its kind (44 instructions, scalar address
+  //    arithmetic included, cost 94 ns however deep the ring).  Per diagonal now 24: the hand-over value is stored by
+  //    every lane through a per-lane LDS index (the boundary lane's points into the hand-over array, the others' into
+  //    a junk area: no exec-mask switch); the neighbour's value is read by every lane from one address, two diagonals
+  //    ahead, straight into the register the DPP shift leaves in the boundary lane (no readlane / move pairs); rows
+  //    of the log-probs and of alpha / beta are reached by running pointers (in bands that cannot leave the arrays)
+  //    instead of clamped 64-bit products.
+  // With 8 wavefronts and more the compute unit's store path is the bound (8 x 512 B of alpha or beta per diagonal).
+  constexpr int kNegOff = 16 * 2 * DB;             // [wavefront][DB] "log 0": what rank 0 reads in place of a neighbour
+  constexpr int kJunkOff = kNegOff + 16 * DB;      // [wavefront][64 + DB]: where the other 63 lanes' stores land
+  __shared__ double lds[kJunkOff + 16 * (64 + DB)];  // first: [boundary between rank r and r + 1][band parity][diagonal]
   const int W = (int)(blockDim.x >> 6);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -307,58 +339,74 @@ __global__ __launch_bounds__(1024) void k_sweep_wide(Ws w, float* __restrict__ c
     b_ = q.x;
     l_ = q.y;
   };
+  if (lane < DB) lds[kNegOff + wv * DB + lane] = kNeg;  // read back by this wavefront only: LDS keeps its order
+  const int hin_of_rank = rank > 0 ? (rank - 1) * 2 * DB : -1;
+  const int boundary_lane = dir == 0 ? 63 : 0;
+  const int hout_junk = kJunkOff + wv * (64 + DB) + lane;
+  auto hin_index = [&](int j) { return hin_of_rank >= 0 ? hin_of_rank + (j & 1) * DB : kNegOff + wv * DB; };
+  auto hout_index = [&](int j) { return lane == boundary_lane ? (rank * 2 + (j & 1)) * DB : hout_junk; };
 
   if (dir == 0) {
     double* alpha = w.alpha + plane + u;
     double a = (u == 0) ? 0.0 : kNeg;
     alpha[0] = a;
     const int nbands = (dlast + DB - 1) / DB;  // diagonals 1 .. dlast
-    const int nsteps = nbands + W - 1;
+    const int nfull = dlast / DB;               // bands wholly inside the lattice; their loads stay below row Dp
     // the ring: diagonal d needs the log-probs of diagonal d - 1
     if (nbands > 0) {
 #pragma unroll
       for (int p = 0; p < P; ++p) load_lp(p, pb[p], pl[p]);
     }
-    for (int s = 0; s < nsteps; ++s) {
-      const int j = s - rank;
-      if (j >= 0 && j < nbands) {  // uniform in the wavefront
-        const int d0 = 1 + j * DB;
-        // the neighbour's hand-over values of this band (written in the pass before): lane i holds diagonal d0 + i
-        double hin = kNeg;
-        if (rank > 0 && lane < DB) hin = hand[rank - 1][j & 1][lane];
-        {  // waited for here, once: otherwise every diagonal's first use waits for LDS, its own hand-over write included
-          int hlo = __double2loint(hin), hhi = __double2hiint(hin);
-          asm volatile("" : "+v"(hlo), "+v"(hhi));
-          hin = __hiloint2double(hhi, hlo);
-        }
-        double* hout = hand[rank][j & 1];
-        // A band that lies wholly inside the lattice runs without a branch (every pass the same loads and stores:
-        // the waits for the ring are counted); only an utterance's last, partial band tests each diagonal.
-        auto band = [&](auto whole) {
+    const float2* lq = lp + (size_t)P * U1s;  // the next row of log-probs to request
+    double* ap = alpha + U1s;                 // the next row of alpha
+    auto band = [&](int j, auto whole) {
+      const int d0 = 1 + j * DB;
+      const int hi = hin_index(j), ho = hout_index(j);
+      double hv[3];  // the neighbour's values, requested two diagonals ahead
+      hv[0] = lds[hi];
+      hv[1] = lds[hi + 1];
 #pragma unroll
-          for (int g = 0; g < DB; g += P) {
+      for (int g = 0; g < DB; g += P) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-              const int d = d0 + g + p;
-              if (decltype(whole)::value || d <= dlast) {  // uniform
-                const double el = a + (double)pl[p];
-                if (lane == 63) hout[g + p] = el;
-                const double fill = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hin), g + p),
-                                                     __builtin_amdgcn_readlane(__double2loint(hin), g + p));
-                const double from_left = lane_shift_up(el, fill);
-                a = log2_add(a + (double)pb[p], from_left);
-                alpha[(size_t)d * U1s] = a;
-              }
-              load_lp(d - 1 + P, pb[p], pl[p]);
-              __builtin_amdgcn_sched_barrier(0);
+        for (int p = 0; p < P; ++p) {
+          const int i = g + p, d = d0 + i;
+          if (i + 2 < DB) hv[(i + 2) % 3] = lds[hi + i + 2];
+          if (decltype(whole)::value || d <= dlast) {  // uniform
+            const double el = a + (double)pl[p];
+            lds[ho + i] = el;
+            const double from_left = lane_shift_up(el, hv[i % 3]);
+            a = log2_add(a + (double)pb[p], from_left);
+            if (decltype(whole)::value) {
+              *ap = a;
+              ap += U1s;
+            } else {
+              alpha[(size_t)d * U1s] = a;
             }
           }
-        };
-        if (d0 + DB - 1 <= dlast) band(std::true_type{});
-        else band(std::false_type{});
+          if (decltype(whole)::value) {
+            const float2 q = *lq;
+            lq += U1s;
+            pb[p] = q.x;
+            pl[p] = q.y;
+          } else {
+            load_lp(d - 1 + P, pb[p], pl[p]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      __syncthreads();
+    };
+    for (int i = 0; i < rank; ++i) band_barrier();  // the lead: rank r starts r bands behind rank 0
+    // Whole bands run without a branch, every pass the same loads and stores in the same order, in a loop that holds
+    // nothing else: the waits for the ring are then counted (vmcnt(N)), the loop never drains its loads.
+    for (int j = 0; j < nfull; ++j) {
+      band(j, std::true_type{});
+      band_barrier();
     }
+    if (nbands > nfull) {  // an utterance's last, partial band tests each diagonal
+      band(nfull, std::false_type{});
+      band_barrier();
+    }
+    for (int i = rank; i < W - 1; ++i) band_barrier();  // every wavefront meets nbands + W - 1 barriers
     if (u == U) {
       const double ll2 = a + (double)w.rec[((size_t)b * (maxT + 2) + T) * maxU1 + U].x;  // frame T-1 is at index T
       w.ll[b] = ll2;
@@ -368,45 +416,56 @@ __global__ __launch_bounds__(1024) void k_sweep_wide(Ws w, float* __restrict__ c
     double* beta = w.beta + plane + u;
     double bt = (u == U) ? 0.0 : kNeg;  // virtual diagonal dlast + 1
     const int nbands = (dlast + 1 + DB - 1) / DB;  // diagonals dlast .. 0
-    const int nsteps = nbands + W - 1;
+    const int nfull = max(dlast - P + 1, 0) / DB;   // bands whose requests (P rows ahead) stay at or above row 0
 #pragma unroll
     for (int p = 0; p < P; ++p) load_lp(dlast - p, pb[p], pl[p]);
-    for (int s = 0; s < nsteps; ++s) {
-      const int j = s - rank;
-      if (j >= 0 && j < nbands) {
-        const int d0 = dlast - j * DB;
-        double hin = kNeg;
-        if (rank > 0 && lane < DB) hin = hand[rank - 1][j & 1][lane];
-        {  // waited for here, once: otherwise every diagonal's first use waits for LDS, its own hand-over write included
-          int hlo = __double2loint(hin), hhi = __double2hiint(hin);
-          asm volatile("" : "+v"(hlo), "+v"(hhi));
-          hin = __hiloint2double(hhi, hlo);
-        }
-        double* hout = hand[rank][j & 1];
-        auto band = [&](auto whole) {
+    const float2* lq = lp + (size_t)max(dlast - P, 0) * U1s;
+    double* bp = beta + (size_t)dlast * U1s;
+    auto band = [&](int j, auto whole) {
+      const int d0 = dlast - j * DB;
+      const int hi = hin_index(j), ho = hout_index(j);
+      double hv[3];
+      hv[0] = lds[hi];
+      hv[1] = lds[hi + 1];
 #pragma unroll
-          for (int g = 0; g < DB; g += P) {
+      for (int g = 0; g < DB; g += P) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-              const int d = d0 - g - p;
-              if (decltype(whole)::value || d >= 0) {  // uniform
-                if (lane == 0) hout[g + p] = bt;
-                const double fill = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hin), g + p),
-                                                     __builtin_amdgcn_readlane(__double2loint(hin), g + p));
-                const double from_right = lane_shift_down(bt, fill);
-                bt = log2_add(bt + (double)pb[p], from_right + (double)pl[p]);
-                beta[(size_t)d * U1s] = bt;
-              }
-              load_lp(d - P, pb[p], pl[p]);
-              __builtin_amdgcn_sched_barrier(0);
+        for (int p = 0; p < P; ++p) {
+          const int i = g + p, d = d0 - i;
+          if (i + 2 < DB) hv[(i + 2) % 3] = lds[hi + i + 2];
+          if (decltype(whole)::value || d >= 0) {  // uniform
+            lds[ho + i] = bt;
+            const double from_right = lane_shift_down(bt, hv[i % 3]);
+            bt = log2_add(bt + (double)pb[p], from_right + (double)pl[p]);
+            if (decltype(whole)::value) {
+              *bp = bt;
+              bp -= U1s;
+            } else {
+              beta[(size_t)d * U1s] = bt;
             }
           }
-        };
-        if (d0 - (DB - 1) >= 0) band(std::true_type{});
-        else band(std::false_type{});
+          if (decltype(whole)::value) {
+            const float2 q = *lq;
+            lq -= U1s;
+            pb[p] = q.x;
+            pl[p] = q.y;
+          } else {
+            load_lp(d - P, pb[p], pl[p]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      __syncthreads();
+    };
+    for (int i = 0; i < rank; ++i) band_barrier();
+    for (int j = 0; j < nfull; ++j) {
+      band(j, std::true_type{});
+      band_barrier();
     }
+    for (int j = nfull; j < nbands; ++j) {  // the bands next to row 0: clamped requests, each diagonal tested
+      band(j, std::false_type{});
+      band_barrier();
+    }
+    for (int i = rank; i < W - 1; ++i) band_barrier();
     if (u == 0) w.ll[B + b] = bt;
   }
 }

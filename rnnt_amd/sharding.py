@@ -60,9 +60,13 @@ MODEL_SKEW_BPS = 1.5e12  # re-ordering pass in front of the wide sweep (16 bytes
 
 def _sweep_step_s(max_u1: int) -> float:
     """Seconds per anti-diagonal of the lattice sweeps: one wavefront per direction up to 128 label positions
-    (one or two columns per lane), above that one wavefront per 64 columns, whose pace hardly depends on the
-    width (measured 121-134 ns at 200 positions, 161-173 at 400)."""
-    return 60e-9 if max_u1 <= 64 else 92e-9 if max_u1 <= 128 else 110e-9 + 0.15e-9 * max_u1
+    (one or two columns per lane), above that one wavefront per 64 columns (measured 82 ns at 200 positions;
+    160 ns at 400, where eight wavefronts' stores share one compute unit)."""
+    if max_u1 <= 64:
+        return 60e-9
+    if max_u1 <= 128:
+        return 92e-9
+    return 66e-9 + 0.08e-9 * max_u1 + 0.46e-9 * max(max_u1 - 256, 0)
 
 
 def shard_seconds(input_lengths: Sequence[int], label_lengths: Sequence[int], indices: Sequence[int], V: int) -> float:
@@ -88,7 +92,8 @@ def _model_seconds_np(n, t_max, u1_max, cells, V: int):
     """_model_seconds on arrays (same arithmetic, element by element)."""
     rows = n * t_max * u1_max
     row_bytes = 4.0 * V
-    step = np.where(u1_max <= 64, 60e-9, np.where(u1_max <= 128, 92e-9, 110e-9 + 0.15e-9 * u1_max))
+    step = np.where(u1_max <= 64, 60e-9, np.where(u1_max <= 128, 92e-9,
+                    66e-9 + 0.08e-9 * u1_max + 0.46e-9 * np.maximum(u1_max - 256, 0)))
     skew = np.where(u1_max > 128, 16.0 * rows / MODEL_SKEW_BPS, 0.0)
     return (cells * row_bytes * (1.0 + MODEL_UNPRUNED) / MODEL_READ_BPS + rows * row_bytes / MODEL_WRITE_BPS +
             (t_max + u1_max) * step + skew + MODEL_LAUNCH_S)
