@@ -44,7 +44,7 @@
  *     thresholds do not affect each other;
  *   - every function returns an rnnt_mi355x_status; nothing throws or aborts.
  *
- * Limits: 1 <= maxU1 <= 1024, B*maxT*maxU1 < 2^31, (maxT+2)*maxU1 < 2^28,
+ * Limits: 1 <= maxU1 <= 1024, B*maxT*maxU1 < 2^31, (maxT+maxU1+32)*maxU1 < 2^27,
  * V >= 1.  Element offsets into logits are 64-bit.
  */
 #ifndef RNNT_MI355X_H_

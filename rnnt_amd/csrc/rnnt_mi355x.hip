@@ -153,8 +153,9 @@ int check_shape(int B, int maxT, int maxU1, int V, int blank) {
   if (blank < 0 || blank >= V) return RNNT_MI355X_INVALID_VALUE;
   if (maxU1 > kMaxU1) return RNNT_MI355X_UNSUPPORTED_SIZE;
   if ((long long)B * maxT * maxU1 >= (1LL << 31)) return RNNT_MI355X_UNSUPPORTED_SIZE;
-  // the sweeps address an utterance's records with 32-bit byte offsets and 24-bit frame indices
-  if (((long long)maxT + 2) * maxU1 >= (1LL << 28) || maxT >= (1 << 24) - 2) return RNNT_MI355X_UNSUPPORTED_SIZE;
+  // the sweeps address an utterance's records with signed 32-bit byte offsets (16 bytes a record; their cursors run
+  // up to maxU1 + 32 frames past either end before they are clamped) and 24-bit frame indices
+  if (((long long)maxT + maxU1 + 32) * maxU1 >= (1LL << 27) || maxT >= (1 << 24) - 2) return RNNT_MI355X_UNSUPPORTED_SIZE;
   return RNNT_MI355X_OK;
 }
 

@@ -19,26 +19,17 @@ namespace {
 // outside the lattice are handled by masking the log-probs that lead into or
 // out of them to "log 0": their alpha/beta then evaluate to ~-1e30 by
 // themselves.  The log-prob rows of the next P diagonals are kept in flight in
-// a register ring.  A diagonal costs the latency of one dependent chain
-// (add, shift, subtract, exp2, log2, add), not issue slots: splitting the
-// columns of a direction over two wavefronts (one column per lane, boundary
-// value through LDS two diagonals ahead, one s_barrier per diagonal) measured
-// 2.5x slower, 207 us against 83 us at T=400, U=100.  Carrying alpha and beta
-// in the linear domain as (float64 mantissa, int32 exponent) pairs -- multiply,
-// ldexp, add, frexp instead of exp2/log2 on the chain -- gave the same results
-// and was also slower (one column per lane 77 us against 61 us, two columns
-// 135 us against 76 us at T=500): the float64 ldexp/frexp steps cost more than
-// the transcendentals they replace.  A second multi-wavefront form without a barrier on the chain -- one column per
-// lane, wavefront w owning columns 64w..64w+63, the one number per diagonal a wavefront needs from its neighbour left
-// in an LDS array indexed by the diagonal, progress counters looked at every 64 diagonals so that a wavefront just
-// trails its neighbour -- was correct and gave 117 us against 158 us at U+1 = 200 and 235 us against 440 us at
-// U+1 = 400 (T=500, B=32), but 59 us against 55 us at U+1 = 101 and nothing at B=128: every wavefront's load of a
-// diagonal touches 64 cache lines and the compute unit's vector cache takes them one per cycle whichever wavefront
-// asks, so W wavefronts cost ~35 ns x W per diagonal.  Not kept: its gain is confined to long label sequences in
-// small batches.  Measured per diagonal: 109 ns with one
-// column per lane, 127 ns with two, 230 ns with four, 494 ns with eight.  Cutting the loop from 30 to 24
-// instructions per diagonal (constant row stride, leaner address arithmetic, shifts that keep the boundary lane's
-// "log 0") brought 105 / 122 / 225 / 488 ns: the dependent chain, not instruction issue, sets the pace.
+// a register ring.  With the ring deep enough a diagonal costs the longer of its dependent chain (add, shift,
+// subtract, exp2, log2, add: ~50 ns) and of what the wavefront issues (~2 ns an instruction of any kind).
+// Forms measured and rejected:
+//  * the columns of a direction over two wavefronts, one column per lane, boundary value through LDS two diagonals
+//    ahead, one s_barrier per diagonal: 2.5x slower (207 us against 83 us at T=400, U=100);
+//  * alpha and beta in the linear domain as (float64 mantissa, int32 exponent) pairs -- multiply, ldexp, add, frexp
+//    instead of exp2 / log2 on the chain, same results: one column per lane 77 us against 61 us, two columns 135 us
+//    against 76 us at T=500 (the float64 ldexp / frexp steps cost more than the transcendentals they replace);
+//  * two wavefronts for 65..128 label positions with the hand-over of k_sweep_wide (bands through LDS) and the
+//    records read in place: 74 ns per diagonal plus a band of lead against 83 ns for two columns per lane -- 2 us in
+//    50, not kept; with the re-ordered copy of k_skew_records in front it loses (the copy costs 12-24 us).
 // ---------------------------------------------------------------------------
 // lane i receives lane i-1's value; lane 0 receives `fill`
 __device__ __forceinline__ double lane_shift_up(double v, double fill) {
@@ -75,6 +66,36 @@ __device__ __forceinline__ void load_lp_diag(const float4* rec0, int d, int maxT
   }
 }
 
+// The same records reached by a running byte offset: the loads of a direction ask for consecutive diagonals, so a
+// column's unclamped offset moves by one frame (stride16 bytes) per load and only the clamp is left -- an add, a
+// v_med3_i32 and the load instead of subtract, max, min, multiply-add and the load (the loop costs what it issues).
+// Signed 32-bit offsets: (maxT + maxU1 + 2) * maxU1 * 16 < 2^31 (the shape check).
+template <int K>
+struct RecCursor {
+  int lin[K], lo[K], hi[K];
+  __device__ __forceinline__ void init(int d, int maxT, unsigned stride16, const int (&ucol)[K], const unsigned (&uoff16)[K]) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const bool has = ucol[i] < (1 << 28);  // lanes beyond the last column read frame -1's first record ("log 0")
+      lin[i] = has ? (d + 1 - ucol[i]) * (int)stride16 + (int)uoff16[i] : 0;
+      lo[i] = has ? (int)uoff16[i] : 0;
+      hi[i] = has ? (maxT + 1) * (int)stride16 + (int)uoff16[i] : 0;
+    }
+  }
+  template <int DIR>  // +1: the next load is the next diagonal; -1: the one before
+  __device__ __forceinline__ void load(const float4* rec0, int step16, float (&pb)[K], float (&pl)[K]) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      int off;
+      asm("v_med3_i32 %0, %1, %2, %3" : "=v"(off) : "v"(lin[i]), "v"(lo[i]), "v"(hi[i]));
+      const float2 q = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rec0) + (unsigned)off);
+      pb[i] = q.x;
+      pl[i] = q.y;
+      lin[i] += DIR * step16;
+    }
+  }
+};
+
 template <int K>
 __device__ __forceinline__ void store_row(double* base, int row, int u0, const double (&v)[K]) {
   double* p = base + ((unsigned)row * (64u * K) + (unsigned)u0);  // row stride 64 * K: a constant, so that the rows of
@@ -104,11 +125,13 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
   // Diagonals of log-probs kept in flight ahead of the dependent chain.  A diagonal's loads take ~0.4 us to come
   // back (most hit the vector cache, every eighth goes further) while its arithmetic takes 40-60 ns per column:
   // with 4 in flight the loop waited for memory (109 / 127 ns per diagonal with one / two columns per lane);
-  // 16 / 8 bring 60 / 92 ns.  (24 and 12: 64 / 94 ns.  Wider lanes are bound by their arithmetic: no change.)
-  // Measured and dropped: a one-instruction clamp (v_med3_i32), a running frame index and scalar-base stores cut
-  // two columns per lane from 42 to 37 instructions per diagonal without changing its 92-96 ns; tools/lat_bench.hip
-  // puts an independent instruction of this mix at 2-2.3 ns and v_exp_f32 / v_log_f32 at 3.8 ns on one wavefront,
-  // i.e. ~45 ns per column for the arithmetic alone.
+  // 16 / 8 brought 60 / 92 ns.  (24 and 12: 64 / 94 ns.  Wider lanes are bound by their arithmetic: no change.)
+  // A wavefront that is alone on its SIMD issues an instruction every ~2 ns whatever its kind, so the loop costs
+  // what it issues: the records' running byte offsets (RecCursor: add, v_med3_i32, load per column instead of
+  // subtract, max, min, multiply-add, load), rows of alpha / beta behind a running pointer (immediate offsets inside
+  // an unrolled group) and the bare v_max_f64 took one / two columns per lane from 30 / 40 to 20 / 34 instructions
+  // per diagonal and from 61 / 92 to 54 / 83 ns (one column is then at the pace of its dependent chain; deeper
+  // rings, 12 or 16 diagonals for two columns, and a single wait per diagonal change nothing).
 #ifndef RNNT_SWEEP_P2
 #define RNNT_SWEEP_P2 8
 #endif
@@ -157,6 +180,14 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
 #pragma unroll
     for (int i = 0; i < K; ++i) a[i] = (u0 + i == 0) ? 0.0 : kNeg;
     store_row<K>(alpha, 0, u0, a);
+    double* sp = alpha + (64u * K + (unsigned)u0);  // the next row of alpha (rows are written in order)
+    constexpr bool kCursor = K <= 2;  // (wider lanes are bound by their arithmetic and short of registers)
+    RecCursor<K> cur;
+    if constexpr (kCursor) cur.init(0, maxT, stride16, ucol, uoff16);
+    auto fetch = [&](int dd, float (&b_)[K], float (&l_)[K]) {  // the loads below ask for diagonals 0, 1, 2, ... in order
+      if constexpr (kCursor) cur.template load<1>(rec0, (int)stride16, b_, l_);
+      else load_lp_diag<K>(rec0, dd, maxT, stride16, ucol, uoff16, b_, l_);
+    };
     double from_left = kNeg;
     // one diagonal: a <- alpha(d) from alpha(d-1) and the log-probs of diagonal d-1
     auto step = [&](int d, const float (&pb)[K], const float (&pl)[K]) {
@@ -166,7 +197,8 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
       from_left = lane_shift_up(el[K - 1], from_left);  // lane 0 keeps its "log 0": no constant to re-load
 #pragma unroll
       for (int i = 0; i < K; ++i) a[i] = log2_add(a[i] + (double)pb[i], (i == 0) ? from_left : el[i - 1]);
-      store_row<K>(alpha, d, u0, a);
+      store_row<K>(sp, 0, 0, a);
+      sp += 64 * K;
     };
     int d = 1;
     float pb[P][K], pl[P][K];
@@ -175,19 +207,19 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
     const int rem = dlast % P;
 #pragma unroll
     for (int p = 0; p < P - 1; ++p)
-      if (p < rem) load_lp_diag<K>(rec0, p, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
+      if (p < rem) fetch(p, pb[p], pl[p]);
 #pragma unroll
     for (int p = 0; p < P - 1; ++p)
       if (p < rem) step(1 + p, pb[p], pl[p]);
     d += rem;
     if (d <= dlast) {
 #pragma unroll
-      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec0, d - 1 + p, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
+      for (int p = 0; p < P; ++p) fetch(d - 1 + p, pb[p], pl[p]);
       for (; d <= dlast; d += P) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           step(d + p, pb[p], pl[p]);
-          load_lp_diag<K>(rec0, d + p - 1 + P, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
+          fetch(d + p - 1 + P, pb[p], pl[p]);
           __builtin_amdgcn_sched_barrier(0);  // keep the refill P diagonals ahead of its use
         }
       }
@@ -207,6 +239,14 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
     double bt[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) bt[i] = (u0 + i == U) ? 0.0 : kNeg;
+    double* sp = beta + ((unsigned)dlast * (64u * K) + (unsigned)u0);  // rows dlast, dlast - 1, ... in order
+    constexpr bool kCursor = K <= 2;
+    RecCursor<K> cur;
+    if constexpr (kCursor) cur.init(dlast, maxT, stride16, ucol, uoff16);
+    auto fetch = [&](int dd, float (&b_)[K], float (&l_)[K]) {  // diagonals dlast, dlast - 1, ... in order
+      if constexpr (kCursor) cur.template load<-1>(rec0, (int)stride16, b_, l_);
+      else load_lp_diag<K>(rec0, dd, maxT, stride16, ucol, uoff16, b_, l_);
+    };
     double from_right = kNeg;
     // one diagonal: bt <- beta(d) from beta(d+1) and the log-probs of diagonal d
     auto step = [&](int d, const float (&pb)[K], const float (&pl)[K]) {
@@ -217,26 +257,27 @@ __global__ __launch_bounds__(64) void k_sweep(Ws w, float* __restrict__ costs, c
         nb[i] = log2_add(bt[i] + (double)pb[i], ((i == K - 1) ? from_right : bt[i + 1]) + (double)pl[i]);
 #pragma unroll
       for (int i = 0; i < K; ++i) bt[i] = nb[i];
-      store_row<K>(beta, d, u0, bt);
+      store_row<K>(sp, 0, 0, bt);
+      sp -= 64 * K;
     };
     int d = dlast;
     float pb[P][K], pl[P][K];
     const int rem = (dlast + 1) % P;
 #pragma unroll
     for (int p = 0; p < P - 1; ++p)
-      if (p < rem) load_lp_diag<K>(rec0, dlast - p, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
+      if (p < rem) fetch(dlast - p, pb[p], pl[p]);
 #pragma unroll
     for (int p = 0; p < P - 1; ++p)
       if (p < rem) step(dlast - p, pb[p], pl[p]);
     d -= rem;
     if (d >= 0) {
 #pragma unroll
-      for (int p = 0; p < P; ++p) load_lp_diag<K>(rec0, d - p, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
+      for (int p = 0; p < P; ++p) fetch(d - p, pb[p], pl[p]);
       for (; d >= 0; d -= P) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           step(d - p, pb[p], pl[p]);
-          load_lp_diag<K>(rec0, d - p - P, maxT, stride16, ucol, uoff16, pb[p], pl[p]);
+          fetch(d - p - P, pb[p], pl[p]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }

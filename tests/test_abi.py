@@ -45,7 +45,9 @@ def test_workspace_query_and_shape_validation():
     assert f(0, 10, 10, ctypes.byref(out)) == _lib.INVALID_VALUE
     assert f(1, 10, 1025, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE
     assert f(1 << 12, 1 << 10, 512, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE  # B*T*U1 >= 2^31
-    assert f(1, 1 << 19, 1024, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE         # (maxT+2)*maxU1 >= 2^28
+    assert f(1, 1 << 18, 1024, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE         # (maxT+maxU1+32)*maxU1 >= 2^27
+    assert f(1, (1 << 17) - 1056, 1024, ctypes.byref(out)) == _lib.UNSUPPORTED_SIZE  # ... exactly 2^27
+    assert f(1, (1 << 17) - 1057, 1024, ctypes.byref(out)) == 0                      # ... just below
     assert f(1, 10, 10, None) == _lib.INVALID_VALUE
 
 

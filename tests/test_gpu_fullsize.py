@@ -88,6 +88,28 @@ def test_config3_full_size_properties_and_subset_parity():
     _subset_parity(before, sub, lab[[0, 63]], il[[0, 63]], ll[[0, 63]], blank, [0, 1])
 
 
+def test_longest_lattice_of_128_columns_closed_form():
+    """One utterance at the edge of the shape limit ((maxT + maxU1 + 32) * maxU1 < 2^27: the sweeps' byte offsets into
+    the records end just below 2^31).  Constant logits make every path equally likely, so the cost is known in closed
+    form: -ln C(T-1+U, U) + (T+U) ln V."""
+    import math
+    T, U, V, blank = (1 << 20) - 161, 127, 4, 0
+    assert (T + U + 1 + 32) * (U + 1) < (1 << 27) <= (T + 1 + U + 1 + 32) * (U + 1)
+    dev = torch.device("cuda:0")
+    x = torch.zeros((1, T, U + 1, V), dtype=torch.float32, device=dev)
+    lab = torch.ones((1, U), dtype=torch.int32, device=dev)
+    run = _run(x, lab, np.array([T], np.int32), np.array([U], np.int32), blank)
+    log_paths = math.lgamma(T + U) - math.lgamma(U + 1) - math.lgamma(T)
+    want = -log_paths + (T + U) * math.log(V)
+    assert abs(run.costs[0].item() - want) < 1e-6 * want
+    assert run.x.sum(-1).abs().max().item() < 2e-5
+    # the probability of passing through a cell, summed over an anti-diagonal's blank and label moves, is 1:
+    # minus the gradient at the blank and the label column, summed over the first frame's cells and the moves out of
+    # (0, 0), is what leaves the start
+    g00 = run.x[0, 0, 0]
+    assert abs(-(g00[blank] + g00[1]).item() + 2 * 0.25 - 1.0) < 1e-4  # dx = gamma*softmax - moves; gamma(0,0) = 1
+
+
 def test_config2_full_size_subset_parity():
     """B=32 T=500 U=100 V=62, blank=39 (reference util.py:72)."""
     B, T, U, V, blank = 32, 500, 100, 62, 39
