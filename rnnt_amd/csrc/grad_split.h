@@ -126,28 +126,54 @@ __global__ __launch_bounds__(kClassifyBlock) void k_classify_rows(const int32_t*
     const int u = rc_row - t * maxU1;
     tt[it] = t; uu[it] = u;
     const size_t ci = ((size_t)b * w.D + (t + u)) * U1s + u;
-    const size_t ci_t = (t + u + 1 < w.D) ? ci + U1s : ci;
-    const size_t ci_u = (u + 1 < U1s) ? ci_t + 1 : ci_t;
     // Lattice state of more than the memory-side cache holds is read past the caches: lines that ordinary loads
     // leave there are not displaced by the streaming kernels that follow, which then run a quarter slower for
     // as long as they last (measured: the zero-fill of a 52 GB tensor 5.0-5.9 instead of 7.05 TB/s after 1.2 GB of
-    // ordinary loads here).  Smaller state stays cached: beta is read three times, by neighbouring threads.
+    // ordinary loads here).  Smaller state stays cached.
     const float4* rcp = &w.rec[((size_t)b * (gm.maxT + 2) + 1 + t) * maxU1 + u];
     raw[it].ll = ll2;
     if (gm.nt) {  // (block-uniform)
       raw[it].a = __builtin_nontemporal_load(&w.alpha[ci]);
       raw[it].be = __builtin_nontemporal_load(&w.beta[ci]);
-      raw[it].be_t = __builtin_nontemporal_load(&w.beta[ci_t]);
-      raw[it].be_u = __builtin_nontemporal_load(&w.beta[ci_u]);
       const f4v r4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(rcp));
       raw[it].rc = make_float4(r4[0], r4[1], r4[2], r4[3]);
     } else {
-      raw[it].a = w.alpha[ci]; raw[it].be = w.beta[ci]; raw[it].be_t = w.beta[ci_t]; raw[it].be_u = w.beta[ci_u];
+      raw[it].a = w.alpha[ci]; raw[it].be = w.beta[ci];
       raw[it].rc = *rcp;
     }
     int lab = 0;
     if (maxU1 > 1) lab = labels[(size_t)b * (maxU1 - 1) + min(u, maxU1 - 2)];
     raw[it].lab = (lab < 0 || lab >= gm.V) ? 0 : lab;
+  }
+  // beta(t+1,u) and beta(t,u+1) are the beta of rows maxU1 and 1 further on: they come from the threads that loaded
+  // them, through LDS (alpha and beta are stored by anti-diagonal, so a wavefront's 64 rows are 64 different sectors
+  // per load: two such loads per row instead of four), the maxU1 rows behind the region's end from a few more loads.
+  // (Used only where the move stays inside the lattice, i.e. where that row is a cell of the same utterance.)
+  constexpr int kHalo = (kMaxU1 + kClassifyBlock - 1) / kClassifyBlock;
+  __shared__ double be_s[kRegionRows + kHalo * kClassifyBlock];
+  double halo[kHalo];
+#pragma unroll
+  for (int h = 0; h < kHalo; ++h) {
+    const int hr = h * kClassifyBlock + (int)threadIdx.x;
+    halo[h] = 0.0;
+    if (hr < maxU1) {  // (needed rows lie inside the utterance; the others' values are not used)
+      const int row = (reg + 1) * kRegionRows + hr;
+      const int rc_row = row < gm.rows_utt ? row : 0;
+      const int t = rc_row / maxU1, u = rc_row - t * maxU1;
+      const double* bp = &w.beta[((size_t)b * w.D + (t + u)) * U1s + u];
+      halo[h] = gm.nt ? __builtin_nontemporal_load(bp) : *bp;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < kClassifyIters; ++it) be_s[it * kClassifyBlock + (int)threadIdx.x] = raw[it].be;
+#pragma unroll
+  for (int h = 0; h < kHalo; ++h) be_s[kRegionRows + h * kClassifyBlock + (int)threadIdx.x] = halo[h];
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kClassifyIters; ++it) {
+    const int local_row = it * kClassifyBlock + (int)threadIdx.x;
+    raw[it].be_t = be_s[local_row + maxU1];
+    raw[it].be_u = be_s[local_row + 1];
   }
   __shared__ int wcnt[2][kClassifyIters][NW];  // full rows / sparse rows per (iteration, wavefront)
   __shared__ int cnt_s[2][NW];
