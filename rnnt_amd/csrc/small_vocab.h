@@ -83,26 +83,59 @@ __device__ __forceinline__ void small_decode(long long row, const SmallGeom& g, 
 // log-sum-exp2 of one row held in LDS (row-per-lane); VEC = widest aligned access of a row
 // Base-2 maximum m2 and log2 of the sum of 2^(x*log2e - m2) of one row; the log-sum-exp is m2 + ls, and a
 // log-probability is (x*log2e - m2) - ls, whose error scales with the distance from the maximum.
+// kRowChunk floats of a row in LDS, every read issued before the first is used: a lane walks its row alone, so a loop
+// of one read and its use per step pays the LDS round trip per step (31 of them per pass at V = 62).  FULL: the chunk
+// lies inside the row.  Otherwise the addresses are clamped to the row's last vector and what lies at or beyond V
+// comes back as `fill`.
+// Measured (V = 62; B=8, T=150, U=40 / B=32, T=500, U=100): first pass 17 -> 9 us / 81 -> 77 us with chunks of 16;
+// gradient pass 19 -> 14 us / 136 -> 135 us with chunks of 8 or 4, 15 / 166 us with 16 (its code then spills scalars).
+constexpr int kRowChunk = 16;
+#ifndef RNNT_SMALL_GRAD_CHUNK
+#define RNNT_SMALL_GRAD_CHUNK 8
+#endif
+constexpr int kGradChunk = RNNT_SMALL_GRAD_CHUNK;
+template <int VEC, bool FULL, int CH>
+__device__ __forceinline__ void small_row_chunk(const float* rowp, int i, int V, float fill, float (&c)[CH]) {
+  static_assert(CH % 4 == 0, "whole vectors of any width");
+#pragma unroll
+  for (int k = 0; k < CH; k += VEC) {
+    const int at = FULL ? i + k : min(i + k, V - VEC);
+    if constexpr (VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(rowp + at); c[k] = q.x; c[k + 1] = q.y; c[k + 2] = q.z; c[k + 3] = q.w; }
+    else if constexpr (VEC == 2) { const float2 q = *reinterpret_cast<const float2*>(rowp + at); c[k] = q.x; c[k + 1] = q.y; }
+    else { c[k] = rowp[at]; }
+  }
+  if constexpr (!FULL) {
+#pragma unroll
+    for (int k = 0; k < CH; ++k) c[k] = (i + k - (k % VEC) < V) ? c[k] : fill;  // (uniform; V is a multiple of VEC)
+  }
+}
+
 template <int VEC>
 __device__ __forceinline__ void small_row_lse2(const float* rowp, int V, float& m2, float& ls) {
   float m = -INFINITY;
-  for (int i = 0; i < V; i += VEC) {
-    float c[VEC];
-    if constexpr (VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(rowp + i); c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w; }
-    else if constexpr (VEC == 2) { const float2 q = *reinterpret_cast<const float2*>(rowp + i); c[0] = q.x; c[1] = q.y; }
-    else { c[0] = rowp[i]; }
+  float c[kRowChunk];
+  int i = 0;
+  for (; i + kRowChunk <= V; i += kRowChunk) {
+    small_row_chunk<VEC, true, kRowChunk>(rowp, i, V, -INFINITY, c);
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) m = fmaxf(m, c[q]);
+    for (int k = 0; k < kRowChunk; ++k) m = fmaxf(m, c[k]);
+  }
+  if (i < V) {
+    small_row_chunk<VEC, false, kRowChunk>(rowp, i, V, -INFINITY, c);
+#pragma unroll
+    for (int k = 0; k < kRowChunk; ++k) m = fmaxf(m, c[k]);
   }
   m2 = m * kLog2e;
   float s = 0.f;
-  for (int i = 0; i < V; i += VEC) {
-    float c[VEC];
-    if constexpr (VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(rowp + i); c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w; }
-    else if constexpr (VEC == 2) { const float2 q = *reinterpret_cast<const float2*>(rowp + i); c[0] = q.x; c[1] = q.y; }
-    else { c[0] = rowp[i]; }
+  for (i = 0; i + kRowChunk <= V; i += kRowChunk) {
+    small_row_chunk<VEC, true, kRowChunk>(rowp, i, V, -INFINITY, c);
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) s += fast_exp2(__builtin_fmaf(c[q], kLog2e, -m2));
+    for (int k = 0; k < kRowChunk; ++k) s += fast_exp2(__builtin_fmaf(c[k], kLog2e, -m2));
+  }
+  if (i < V) {  // (2^-inf = 0 for what lies beyond the row)
+    small_row_chunk<VEC, false, kRowChunk>(rowp, i, V, -INFINITY, c);
+#pragma unroll
+    for (int k = 0; k < kRowChunk; ++k) s += fast_exp2(__builtin_fmaf(c[k], kLog2e, -m2));
   }
   ls = fast_log2(s);
 }
@@ -367,23 +400,36 @@ __device__ __forceinline__ float small_row_grad(const float* src, float* dst, in
   const float c2 = cf.x, pb = cf.y, pl = cf.z;
   const int lab = __float_as_int(cf.w);
   float sq = 0.f;
-  for (int i = 0; i < V; i += VEC) {
-    float c[VEC];
-    if constexpr (VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(src + i); c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w; }
-    else if constexpr (VEC == 2) { const float2 q = *reinterpret_cast<const float2*>(src + i); c[0] = q.x; c[1] = q.y; }
-    else { c[0] = src[i]; }
+  float c[kGradChunk];
+  auto work = [&](int i) {  // (an element beyond the row arrives as -inf and leaves as 0: it is neither blank nor label)
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) {
-      float gv = fast_exp2(__builtin_fmaf(c[q], kLog2e, c2));
-      gv -= (i + q == blank) ? pb : 0.f;
-      gv -= (i + q == lab) ? pl : 0.f;
+    for (int k = 0; k < kGradChunk; ++k) {
+      float gv = fast_exp2(__builtin_fmaf(c[k], kLog2e, c2));
+      gv -= (i + k == blank) ? pb : 0.f;
+      gv -= (i + k == lab) ? pl : 0.f;
       gv *= sc;
       sq = __builtin_fmaf(gv, gv, sq);
-      c[q] = gv;
+      c[k] = gv;
     }
-    if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + i) = make_float4(c[0], c[1], c[2], c[3]);
-    else if constexpr (VEC == 2) *reinterpret_cast<float2*>(dst + i) = make_float2(c[0], c[1]);
-    else dst[i] = c[0];
+  };
+  auto put = [&](int at, int k) {
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + at) = make_float4(c[k], c[k + 1], c[k + 2], c[k + 3]);
+    else if constexpr (VEC == 2) *reinterpret_cast<float2*>(dst + at) = make_float2(c[k], c[k + 1]);
+    else dst[at] = c[k];
+  };
+  int i = 0;
+  for (; i + kGradChunk <= V; i += kGradChunk) {
+    small_row_chunk<VEC, true, kGradChunk>(src, i, V, -INFINITY, c);
+    work(i);
+#pragma unroll
+    for (int k = 0; k < kGradChunk; k += VEC) put(i + k, k);
+  }
+  if (i < V) {
+    small_row_chunk<VEC, false, kGradChunk>(src, i, V, -INFINITY, c);
+    work(i);
+#pragma unroll
+    for (int k = 0; k < kGradChunk; k += VEC)
+      if (i + k < V) put(i + k, k);  // (uniform)
   }
   return sq;
 }
