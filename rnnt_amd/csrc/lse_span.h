@@ -106,19 +106,55 @@ __global__ __launch_bounds__(kLseWaves * 64) void k_lse_span(const float* __rest
       atomicOr(&w.hdr->flags, RNNT_MI355X_FLAG_BAD_LABEL);
       lb = 0;
     }
-    float mx = -INFINITY, cl = 0.f;
-    float cb = 0.f;
+    // The label's and the blank's logit out of the row's registers (no one-lane loads next to the row loads).
+    float mx = -INFINITY, xl;
+    if constexpr (NC < 16) {  // a compare and a select per element and symbol: only the lane that holds it picks it
+      float cl = 0.f, cb = 0.f;
 #pragma unroll
-    for (int i = 0; i < NC; ++i)
+      for (int i = 0; i < NC; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        mx = fmaxf(mx, v[g][i][q]);
-        cl = ((j + L * i) * 4 + q == lb) ? v[g][i][q] : cl;  // only the lane that holds the label's logit picks it
-        cb = ((j + L * i) * 4 + q == blank) ? v[g][i][q] : cb;  // likewise the blank's
-      }
-    mx = group_max<L>(mx);
-    const float xl = __shfl(cl, r * L + ((lb >> 2) & (L - 1)), 64);
-    xb[g] = __shfl(cb, r * L + ((blank >> 2) & (L - 1)), 64);  // (every lane of the group gets it; lane j == 0 uses it)
+        for (int q = 0; q < 4; ++q) {
+          mx = fmaxf(mx, v[g][i][q]);
+          cl = ((j + L * i) * 4 + q == lb) ? v[g][i][q] : cl;
+          cb = ((j + L * i) * 4 + q == blank) ? v[g][i][q] : cb;
+        }
+      mx = group_max<L>(mx);
+      xl = __shfl(cl, r * L + ((lb >> 2) & (L - 1)), 64);
+      xb[g] = __shfl(cb, r * L + ((blank >> 2) & (L - 1)), 64);  // (every lane of the group gets it; lane j == 0 uses it)
+    } else {
+      // Rows of more than 8 KiB (64 registers per lane): a wavefront's 64 lanes share one row, so the symbol is
+      // wave-uniform -- element e sits in lane (e >> 2) & 63, register (e >> 8) * 4 + (e & 3): a tree of NC * 4 - 1
+      // selects on the bits of the register's number, their conditions scalar, and one readlane per symbol instead of
+      // 2 * NC * 4 compares and selects (B=32, T=250, U=150, V=4096: first pass 2.90 -> 2.84 ms; with 16 registers per
+      // lane, V=1024, the tree's serial scalar steps cost more than they save: 1.57 -> 1.59 ms).
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mx = fmaxf(mx, v[g][i][q]);
+      mx = group_max<L>(mx);
+      static_assert(NC < 16 || L == 64, "one row per wavefront instruction");
+      auto pick = [&](int e) {  // e wave-uniform, 0 <= e < V
+        const int eu = __builtin_amdgcn_readfirstlane(e);
+        // (bit-field inserts under a scalar mask: written as selects, or as an indexed array, the compiler puts the
+        // row's registers into scratch memory to index them)
+        unsigned t[NC * 4];
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t[i * 4 + q] = __float_as_uint(v[g][i][q]);
+        unsigned k = (unsigned)(((eu >> 8) << 2) | (eu & 3));
+#pragma unroll
+        for (int n = NC * 4; n > 1; n >>= 1) {
+          const unsigned odd = 0u - (k & 1u);  // all ones: take the odd one of each pair
+#pragma unroll
+          for (int m = 0; m < n / 2; ++m) asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(t[m]) : "s"(odd), "v"(t[2 * m + 1]), "v"(t[2 * m]));
+          k >>= 1;
+        }
+        return __int_as_float(__builtin_amdgcn_readlane((int)t[0], (eu >> 2) & 63));
+      };
+      xl = pick(lb);
+      xb[g] = pick(blank);
+    }
     const float m2 = (state[g] ? mx : 0.f) * kLog2e;  // rows without a cell keep m = 0 so that nothing below is NaN
     float s = 0.f;
 #pragma unroll
